@@ -1,0 +1,716 @@
+# -*- coding: utf-8 -*-
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing under pytorch-vae_amd/ may import this file.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as
+the checker / the reported CPU baseline, never as the thing that is shipped or measured
+as the product.
+
+What it is: a from-scratch CPU restatement (plain torch fp32 tensor math + torch autograd,
+no nn.Transformer / nn.MultiheadAttention modules) of the reference hot path
+
+    VQVAEExperiment.training_step      /root/reference/experiment.py:453-476
+      -> VQVAE.forward                 /root/reference/models/vq_vae.py:767-901
+         -> encode                     models/vq_vae.py:639-660
+         -> LatentTokenizer / to_code  models/vq_vae.py:310-322, 736-743
+         -> VectorQuantizerEMA.forward models/vq_vae.py:170-283 (+ _ema_update :77-89)
+         -> decode                     models/vq_vae.py:745-765
+      -> VQVAE.loss_function           models/vq_vae.py:1097-1388
+
+The arithmetic the reference delegates to torch modules (third-party, torch==2.6.0 pinned at
+/root/reference/requirements.txt:95; torch 2.10 in this image) is restated from torch's
+published semantics:
+  * nn.TransformerEncoderLayer/DecoderLayer, norm_first=True, relu FFN, dropout 0.1
+  * nn.MultiheadAttention: packed in_proj [3E,E], scale 1/sqrt(dh), additive -inf key padding
+    mask, dropout on the attention probabilities, out_proj
+  * nn.LayerNorm eps=1e-5 (biased variance), nn.GELU (erf form)
+
+Parity pin: the reference has NO tests or golden vectors.  The pin is
+tests/golden/*.npz, produced by tests/golden/make_golden.py, which imports the real reference
+from /root/reference in the build container and records its inputs/outputs; tests/test_oracle.py
+checks this file against those fixtures (and, when /root/reference is present, against the live
+reference).  The state is a flat dict {reference state_dict key -> tensor}, so a reference
+state_dict loads without renaming.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# ----------------------------------------------------------------------------------------------
+# configuration: same constructor keywords as the reference (models/vq_vae.py:366-409)
+# ----------------------------------------------------------------------------------------------
+DEFAULT_CFG = dict(
+    input_dim=6, hidden_dim=512, num_layers=4, num_heads=8, max_seq_len=350,
+    codebook_size=512, code_dim=128, beta=0.25, use_vq=True, residual_vq=False,
+    num_quantizers=1, label_smoothing=0.0, ss_tv_lambda=0.0, usage_entropy_lambda=0.0,
+    xyz_align_alpha=0.7, dist_lambda=0.0, rigid_aug_prob=0.0, pairwise_sample_k=32,
+    codebook_init_path=None, ema_decay_start=0.98, ema_decay_end=0.98, ema_decay_warm_steps=0,
+    soft_vq_use=False, soft_vq_tau_start=2.0, soft_vq_tau_end=0.5, soft_vq_tau_warm_steps=0,
+    soft_vq_alpha_warm_steps=0, noise_warmup_steps=0, max_noise_std=0.0, latent_tokens=32,
+    tokenizer_heads=8, tokenizer_layers=2, tokenizer_dropout=0.1, latent_sigmoid=False,
+    latent_sigmoid_ae_only=True, reinit_dead_codes=True, reinit_prob=1.0,
+    dead_usage_threshold=0, ema_update_freeze_steps=0, print_init=True,
+)
+SS_ENC_LAYERS = 2          # models/vq_vae.py:473
+FFN_DIM = 2048             # torch default dim_feedforward of nn.Transformer*Layer
+LN_EPS = 1e-5
+VQ_EPS = 1e-5              # models/vq_vae.py:511
+VQ_DECAY0 = 0.98           # models/vq_vae.py:510
+
+
+def make_cfg(**kw):
+    cfg = dict(DEFAULT_CFG)
+    for k, v in kw.items():
+        if k in cfg:
+            cfg[k] = v          # unknown keys (e.g. "name") are swallowed, models/vq_vae.py:408
+    return cfg
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter shapes (the reference's state_dict)
+# ----------------------------------------------------------------------------------------------
+def _attn_shapes(p, H):
+    return {f"{p}.in_proj_weight": (3 * H, H), f"{p}.in_proj_bias": (3 * H,),
+            f"{p}.out_proj.weight": (H, H), f"{p}.out_proj.bias": (H,)}
+
+
+def _lin_shapes(p, out_f, in_f):
+    return {f"{p}.weight": (out_f, in_f), f"{p}.bias": (out_f,)}
+
+
+def _ln_shapes(p, H):
+    return {f"{p}.weight": (H,), f"{p}.bias": (H,)}
+
+
+def param_shapes(cfg) -> Dict[str, tuple]:
+    H, D = cfg["hidden_dim"], cfg["code_dim"]
+    s: Dict[str, tuple] = {}
+    s.update(_lin_shapes("input_proj", H, 3))
+    s.update(_lin_shapes("ss_input_proj", H, 3))
+    for stack, n in (("encoder", cfg["num_layers"]), ("ss_encoder", SS_ENC_LAYERS)):
+        for i in range(n):
+            p = f"{stack}.layers.{i}"
+            s.update(_attn_shapes(f"{p}.self_attn", H))
+            s.update(_lin_shapes(f"{p}.linear1", FFN_DIM, H))
+            s.update(_lin_shapes(f"{p}.linear2", H, FFN_DIM))
+            s.update(_ln_shapes(f"{p}.norm1", H))
+            s.update(_ln_shapes(f"{p}.norm2", H))
+    for n in ("enc_ln", "ln_geo", "ln_ss", "mem_ln"):
+        s.update(_ln_shapes(n, H))
+    s.update(_lin_shapes("to_code", D, H))
+    s["tokenizer.queries"] = (cfg["latent_tokens"], H)
+    for i in range(cfg["tokenizer_layers"]):
+        p = f"tokenizer.layers.{i}"
+        s.update(_ln_shapes(f"{p}.ln_q", H))
+        s.update(_ln_shapes(f"{p}.ln_kv", H))
+        s.update(_attn_shapes(f"{p}.attn", H))
+        s.update(_ln_shapes(f"{p}.ln_o", H))
+        s.update(_lin_shapes(f"{p}.ffn.0", 4 * H, H))
+        s.update(_lin_shapes(f"{p}.ffn.2", H, 4 * H))
+    s.update(_lin_shapes("fuse_mlp.0", H, 2 * H))
+    s.update(_lin_shapes("fuse_mlp.2", H, H))
+    s.update(_ln_shapes("fuse_mlp.3", H))
+    s.update(_lin_shapes("from_code", H, D))
+    for i in range(cfg["num_layers"]):
+        p = f"decoder.layers.{i}"
+        s.update(_attn_shapes(f"{p}.self_attn", H))
+        s.update(_attn_shapes(f"{p}.multihead_attn", H))
+        s.update(_lin_shapes(f"{p}.linear1", FFN_DIM, H))
+        s.update(_lin_shapes(f"{p}.linear2", H, FFN_DIM))
+        for k in ("norm1", "norm2", "norm3"):
+            s.update(_ln_shapes(f"{p}.{k}", H))
+    s["query_embed.weight"] = (cfg["max_seq_len"], H)
+    s.update(_lin_shapes("head_xyz", 3, H))
+    s.update(_lin_shapes("head_ss", 3, H))
+    return s
+
+
+def buffer_shapes(cfg) -> Dict[str, tuple]:
+    H, D = cfg["hidden_dim"], cfg["code_dim"]
+    b = {"pos_enc": (1, cfg["max_seq_len"], H)}
+    if cfg["use_vq"]:
+        K = cfg["num_quantizers"] * cfg["codebook_size"]
+        b.update({"quantizer.embedding": (K, D), "quantizer.ema_cluster_size": (K,),
+                  "quantizer.ema_embedding": (K, D), "quantizer._ep_usage": (K,),
+                  "quantizer._ep_top1_sum": (1,), "quantizer._ep_top2_sum": (1,),
+                  "quantizer._ep_cnt": (1,), "quantizer._ep_qe_sum": (1,),
+                  "quantizer._ep_qe_hist": (64,)})
+    return b
+
+
+def sinusoid_table(max_len, H):
+    """models/vq_vae.py:478-483: interleaved sin/cos, base 10000."""
+    pe = torch.zeros(max_len, H)
+    pos = torch.arange(max_len, dtype=torch.float32)[:, None]
+    freq = torch.exp(torch.arange(0, H, 2).float() * (-math.log(10000.0) / H))
+    pe[:, 0::2] = torch.sin(pos * freq)
+    pe[:, 1::2] = torch.cos(pos * freq)
+    return pe[None]
+
+
+def random_state(cfg, seed=0) -> Dict[str, Tensor]:
+    """A seeded state for tests that do not need the reference's exact init stream."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in param_shapes(cfg).items():
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k.endswith("norm3.weight") \
+                or (k.endswith(".weight") and len(shp) == 1):
+            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif len(shp) == 1:
+            sd[k] = 0.05 * torch.randn(shp, generator=g)
+        else:
+            sd[k] = torch.randn(shp, generator=g) / math.sqrt(shp[-1])
+    if "query_embed.weight" in sd:
+        sd["query_embed.weight"] = 0.02 * torch.randn(param_shapes(cfg)["query_embed.weight"], generator=g)
+    sd["tokenizer.queries"] = 0.02 * torch.randn(param_shapes(cfg)["tokenizer.queries"], generator=g)
+    for k, shp in buffer_shapes(cfg).items():
+        sd[k] = torch.zeros(shp)
+    sd["pos_enc"] = sinusoid_table(cfg["max_seq_len"], cfg["hidden_dim"])
+    if cfg["use_vq"]:
+        K, D = buffer_shapes(cfg)["quantizer.embedding"]
+        sd["quantizer.embedding"] = torch.randn(K, D, generator=g) / math.sqrt(D)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# primitive ops
+# ----------------------------------------------------------------------------------------------
+def layer_norm(x, w, b):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + LN_EPS) * w + b
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def unit(v, eps=1e-8):
+    """models/vq_vae.py:328-329."""
+    return v / (v.norm(dim=-1, keepdim=True) + eps)
+
+
+class OracleVQVAE:
+    """Functional restatement; `sd` maps reference state_dict keys to tensors (updated in place
+    for the quantizer buffers exactly where the reference mutates its buffers)."""
+
+    def __init__(self, sd: Dict[str, Tensor], drop_scale: float = 1.0, **model_params):
+        self.cfg = make_cfg(**model_params)
+        self.sd = sd
+        self.training = True
+        self.drop_scale = float(drop_scale)     # 0.0 -> every dropout site disabled (parity mode)
+        c = self.cfg
+        self.use_vq = bool(c["use_vq"])
+        self.Q = int(c["num_quantizers"])
+        self.K_per = int(c["codebook_size"])
+        self.K = self.Q * self.K_per
+        self.beta = float(c["beta"])
+        self.decay = VQ_DECAY0
+        self.label_smoothing = float(c["label_smoothing"])
+        self.usage_entropy_lambda = float(c["usage_entropy_lambda"])
+        self.training_steps = 0
+        self.data_mean = None
+        self.data_std = None
+
+    # ---- helpers -----------------------------------------------------------------------
+    def _p(self, k):
+        return self.sd[k]
+
+    def _drop(self, x, p):
+        p = p * self.drop_scale
+        if not self.training or p <= 0.0:
+            return x
+        return F.dropout(x, p=p, training=True)
+
+    def _ln(self, x, name):
+        return layer_norm(x, self._p(name + ".weight"), self._p(name + ".bias"))
+
+    def _lin(self, x, name):
+        return linear(x, self._p(name + ".weight"), self._p(name + ".bias"))
+
+    def _mha(self, q_in, kv_in, name, nheads, key_pad: Optional[Tensor], p_drop):
+        """torch.nn.MultiheadAttention(batch_first=True), need_weights=False.
+        key_pad: [B,S] bool, True = ignore that key."""
+        B, T, E = q_in.shape
+        S = kv_in.shape[1]
+        dh = E // nheads
+        W, bias = self._p(name + ".in_proj_weight"), self._p(name + ".in_proj_bias")
+        q = linear(q_in, W[:E], bias[:E])
+        k = linear(kv_in, W[E:2 * E], bias[E:2 * E])
+        v = linear(kv_in, W[2 * E:], bias[2 * E:])
+        q = q.view(B, T, nheads, dh).transpose(1, 2)
+        k = k.view(B, S, nheads, dh).transpose(1, 2)
+        v = v.view(B, S, nheads, dh).transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+        if key_pad is not None:
+            s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
+        a = torch.softmax(s, dim=-1)
+        a = self._drop(a, p_drop)
+        o = (a @ v).transpose(1, 2).reshape(B, T, E)
+        return linear(o, self._p(name + ".out_proj.weight"), self._p(name + ".out_proj.bias"))
+
+    def _enc_layer(self, x, p, key_pad, nheads):
+        # pre-LN encoder block (torch TransformerEncoderLayer, norm_first=True, relu)
+        h = self._ln(x, p + ".norm1")
+        x = x + self._drop(self._mha(h, h, p + ".self_attn", nheads, key_pad, 0.1), 0.1)
+        h = self._ln(x, p + ".norm2")
+        h = self._drop(torch.relu(self._lin(h, p + ".linear1")), 0.1)
+        return x + self._drop(self._lin(h, p + ".linear2"), 0.1)
+
+    def _dec_layer(self, x, mem, p, tgt_pad, nheads):
+        h = self._ln(x, p + ".norm1")
+        x = x + self._drop(self._mha(h, h, p + ".self_attn", nheads, tgt_pad, 0.1), 0.1)
+        h = self._ln(x, p + ".norm2")
+        x = x + self._drop(self._mha(h, mem, p + ".multihead_attn", nheads, None, 0.1), 0.1)
+        h = self._ln(x, p + ".norm3")
+        h = self._drop(torch.relu(self._lin(h, p + ".linear1")), 0.1)
+        return x + self._drop(self._lin(h, p + ".linear2"), 0.1)
+
+    # ---- model (models/vq_vae.py:639-765) ----------------------------------------------
+    def encode(self, x, mask=None):
+        c = self.cfg
+        L = x.shape[1]
+        pad = (~mask) if mask is not None else None
+        pe = self._p("pos_enc")[:, :L]
+        g = self._drop(self._lin(x[..., :3], "input_proj"), 0.1) + pe          # :642-643
+        for i in range(c["num_layers"]):
+            g = self._enc_layer(g, f"encoder.layers.{i}", pad, c["num_heads"])
+        h_geo = self._ln(g, "enc_ln")                                           # :645
+        g = self._ln(h_geo, "ln_geo")                                           # :646
+        s = self._lin(x[..., 3:], "ss_input_proj") + pe                         # :649-650 (no dropout)
+        for i in range(SS_ENC_LAYERS):
+            s = self._enc_layer(s, f"ss_encoder.layers.{i}", pad, c["num_heads"])
+        h_ss = s
+        s = self._ln(s, "ln_ss")
+        f = torch.cat([g, s], dim=-1)
+        f = self._lin(gelu(self._lin(f, "fuse_mlp.0")), "fuse_mlp.2")
+        return self._ln(f, "fuse_mlp.3"), h_geo, h_ss
+
+    def tokenize_to_codes(self, h, mask=None):
+        c = self.cfg
+        B = h.shape[0]
+        pad = (~mask) if mask is not None else None
+        pdrop = float(c["tokenizer_dropout"])
+        q = self._p("tokenizer.queries")[None].expand(B, -1, -1)
+        for i in range(c["tokenizer_layers"]):
+            p = f"tokenizer.layers.{i}"
+            qn, kvn = self._ln(q, p + ".ln_q"), self._ln(h, p + ".ln_kv")
+            q = q + self._drop(self._mha(qn, kvn, p + ".attn", c["tokenizer_heads"], pad, pdrop), pdrop)
+            f = self._lin(gelu(self._lin(self._ln(q, p + ".ln_o"), p + ".ffn.0")), p + ".ffn.2")
+            q = q + self._drop(f, pdrop)
+        z = self._lin(q, "to_code")
+        if c["latent_sigmoid"] and ((not c["latent_sigmoid_ae_only"]) or (not self.use_vq)):
+            z = torch.sigmoid(z)                                                # :740-742
+        return z
+
+    def decode(self, z, mask=None):
+        c = self.cfg
+        B = z.shape[0]
+        L = mask.shape[1] if mask is not None else c["max_seq_len"]
+        mem = self._ln(self._lin(z, "from_code"), "mem_ln")
+        t = (self._p("query_embed.weight")[:L] + self._p("pos_enc")[0, :L])[None].expand(B, L, -1)
+        pad = (~mask) if mask is not None else None
+        for i in range(c["num_layers"]):
+            t = self._dec_layer(t, mem, f"decoder.layers.{i}", pad, c["num_heads"])
+        return torch.cat([self._lin(t, "head_xyz"), self._lin(t, "head_ss")], dim=-1)
+
+    # ---- quantizer (models/vq_vae.py:77-89, 170-283) -----------------------------------
+    @torch.no_grad()
+    def _ema_update(self, rows, idx):
+        if rows.numel() == 0 or idx.numel() == 0:
+            return
+        K, D = self.K, rows.shape[1]
+        cnt = torch.zeros(K).index_add_(0, idx, torch.ones(idx.shape[0]))
+        ssum = torch.zeros(K, D).index_add_(0, idx, rows)
+        ecs, eemb, emb = (self.sd["quantizer.ema_cluster_size"], self.sd["quantizer.ema_embedding"],
+                          self.sd["quantizer.embedding"])
+        ecs.mul_(self.decay).add_(cnt * (1 - self.decay))
+        eemb.mul_(self.decay).add_(ssum * (1 - self.decay))
+        emb.copy_(eemb / (ecs[:, None] + VQ_EPS))
+
+    @staticmethod
+    def _nearest(rows, table):
+        d = (rows.pow(2).sum(1, keepdim=True) - 2.0 * (rows @ table.t())
+             + table.pow(2).sum(1, keepdim=True).t())
+        return torch.argmin(d, dim=1), d
+
+    @torch.no_grad()
+    def _usage_stats(self, idx_flat):
+        use = torch.bincount(idx_flat, minlength=self.K).float()
+        p = use / use.sum().clamp_min(1.0)
+        nz = p > 0
+        ppl = torch.exp(-(p[nz] * p[nz].log()).sum()) if bool(nz.any()) else torch.tensor(0.0)
+        dead = (use == 0).float().mean()
+        return use, ppl, dead
+
+    def quantize(self, z_e, do_ema_update=True):
+        B, M, D = z_e.shape
+        flat = z_e.reshape(-1, D)
+        emb = self.sd["quantizer.embedding"]
+        upd = self.training and do_ema_update
+        if self.Q == 1:
+            idx, _ = self._nearest(flat, emb)
+            z_q = emb[idx].view(B, M, D)          # gather BEFORE the EMA refresh (:189 vs :191)
+            if upd:
+                self._ema_update(flat.detach(), idx)
+            idx_all, idx_out = idx, idx.view(B, M)
+        else:
+            res, levels, parts = flat, [], []
+            for lv in range(self.Q):
+                lo = lv * self.K_per
+                tab = emb[lo:lo + self.K_per]     # a VIEW: level lv+1 sees lv's refresh (:236)
+                i_l, _ = self._nearest(res, tab)
+                zq_l = tab[i_l]                   # gathered copy, taken before this level's refresh
+                levels.append(i_l + lo)
+                parts.append(zq_l)
+                if upd:
+                    self._ema_update(res.detach(), i_l + lo)
+                res = res - zq_l
+            idx_all = torch.cat(levels, 0)        # level-major flat [Q*B*M] (:260)
+            idx_out = idx_all
+            z_q = torch.stack(parts, 0).sum(0).view(B, M, D)
+        z_st = z_e + (z_q - z_e).detach()
+        use, ppl, dead = self._usage_stats(idx_all)
+        with torch.no_grad():
+            self.sd["quantizer._ep_usage"].add_(use)
+            self.sd["quantizer._ep_cnt"].add_(float(idx_all.shape[0]))
+        return z_st, z_q, idx_out, torch.stack([ppl, dead])
+
+    # ---- forward (models/vq_vae.py:767-901); aug/noise/soft-VQ/re-init excluded: they draw
+    # from the global torch RNG or are disabled in both shipped configs (SURVEY 8a a13,a14) ----
+    def forward(self, x, mask=None):
+        c = self.cfg
+        target = x.clone()
+        if self.use_vq:
+            ws = c["ema_decay_warm_steps"]
+            if ws <= 0:
+                self.decay = float(c["ema_decay_end"])
+            else:
+                t = min(1.0, max(0.0, self.training_steps) / float(ws))
+                self.decay = float((1.0 - t) * c["ema_decay_start"] + t * c["ema_decay_end"])
+        h, _, _ = self.encode(x, mask)
+        if self.training:
+            self.training_steps += 1
+        z_e = self.tokenize_to_codes(h, mask)
+        if not self.use_vq:
+            z_dec, z_q = z_e, z_e
+            idx = torch.zeros(z_e.shape[0], z_e.shape[1], dtype=torch.long)
+            ppl = dead = torch.tensor(0.0)
+        else:
+            upd = self.training and (self.training_steps >= c["ema_update_freeze_steps"])
+            z_dec, z_q, idx, st = self.quantize(z_e, do_ema_update=upd)
+            ppl, dead = st[0], st[1]
+        recons = self.decode(z_dec, mask)
+        return [recons, target, (z_q, z_e, idx, ppl, dead), mask]
+
+    # ---- loss (models/vq_vae.py:1097-1388) ----------------------------------------------
+    @staticmethod
+    def _per_sample_mse(a, b, mask):
+        d2 = (a - b).pow(2).sum(-1)
+        if mask is None:
+            return d2.mean(1)
+        m = mask.float()
+        return (d2 * m).sum(1) / m.sum(1).clamp_min(1.0)
+
+    @staticmethod
+    def _mmean(v, m):
+        """masked mean over everything; m None -> plain mean."""
+        if m is None:
+            return v.mean()
+        m = m.float()
+        return (v * m).sum() / m.sum().clamp_min(1.0)
+
+    @staticmethod
+    def kabsch(a, b, mask):
+        """models/vq_vae.py:943-965: rotation R (row-vector convention x@R) and shift t, no grad."""
+        with torch.no_grad():
+            if mask is None:
+                a_mu, b_mu = a.mean(1, keepdim=True), b.mean(1, keepdim=True)
+                a_c, b_c = a - a_mu, b - b_mu
+                Hm = torch.einsum("bli,blj->bij", a_c, b_c)
+            else:
+                m = mask.float()[..., None]
+                den = m.sum(1, keepdim=True).clamp_min(1.0)
+                a_mu, b_mu = (a * m).sum(1, keepdim=True) / den, (b * m).sum(1, keepdim=True) / den
+                a_c, b_c = a - a_mu, b - b_mu
+                Hm = torch.einsum("bli,blj->bij", a_c * m, b_c)
+            U, _, Vh = torch.linalg.svd(Hm)
+            sgn = (torch.det(U @ Vh) >= 0).float() * 2.0 - 1.0
+            Dm = torch.eye(3).repeat(a.shape[0], 1, 1)
+            Dm[:, 2, 2] = sgn
+            R = U @ Dm @ Vh
+            t = b_mu - a_mu @ R
+            ok = torch.isfinite(R).all(dim=(1, 2)) & torch.isfinite(t).all(dim=(1, 2))
+        return R, t, ok
+
+    @staticmethod
+    def _dihedral(x):
+        """models/vq_vae.py:347-359 -> [B, L-3, 2] (cos, sin)."""
+        b1 = unit(x[:, 1:-2] - x[:, :-3])
+        b2 = unit(x[:, 2:-1] - x[:, 1:-2])
+        b3 = unit(x[:, 3:] - x[:, 2:-1])
+        n1 = unit(torch.cross(b1, b2, dim=-1))
+        n2 = unit(torch.cross(b2, b3, dim=-1))
+        m1 = torch.cross(n1, unit(b2), dim=-1)
+        co = (n1 * n2).sum(-1, keepdim=True).clamp(-1.0, 1.0)
+        si = (m1 * n2).sum(-1, keepdim=True).clamp(-1.0, 1.0)
+        return torch.cat([co, si], -1)
+
+    def _local_pdm(self, a, b, mask, window):
+        L = a.shape[1]
+        if L < 2 or window <= 1:
+            return torch.tensor(0.0)
+        acc, n = 0.0, 0.0
+        for d in range(1, window):
+            da = (a[:, :-d] - a[:, d:]).norm(dim=-1)
+            db = (b[:, :-d] - b[:, d:]).norm(dim=-1)
+            m = (mask[:, :-d] & mask[:, d:]) if mask is not None else None
+            acc = acc + self._mmean((da - db).pow(2), m)
+            n += 1.0
+        return acc / max(1.0, n)
+
+    def _window_kabsch(self, a, b, mask, win, stride):
+        B, L, _ = a.shape
+        if L < 3 or win < 3:
+            return torch.tensor(0.0)
+        acc, nwin = 0.0, 0
+        for s in range(0, L - win + 1, max(1, stride)):
+            aw, bw = a[:, s:s + win], b[:, s:s + win]
+            sm = mask[:, s:s + win] if mask is not None else None
+            if sm is not None:
+                enough = sm.sum(1) >= 3
+                if not bool(enough.any()):
+                    continue
+            R, t, ok = self.kabsch(aw, bw, sm)
+            if sm is not None:
+                ok = ok & enough
+            if not bool(ok.any()):
+                continue
+            al = aw @ R + t
+            if sm is None:
+                mse = ((al - bw) ** 2).mean(dim=(1, 2))
+                sel = ok
+            else:
+                m = sm.float()[..., None]
+                mse = ((al - bw) ** 2 * m).sum(dim=(1, 2)) / m.sum(dim=(1, 2)).clamp_min(1.0)
+                sel = enough & ok
+            if bool(sel.any()):
+                acc = acc + mse[sel].mean()
+                nwin += 1
+        return torch.tensor(0.0) if nwin == 0 else acc / float(nwin)
+
+    def _frenet(self, a, mask):
+        L = a.shape[1]
+        if L >= 3:
+            d1 = a[:, 1:] - a[:, :-1]
+            kap = (d1[:, 1:] - d1[:, :-1]).pow(2).sum(-1)
+            m = (mask[:, 2:] & mask[:, 1:-1] & mask[:, :-2]) if mask is not None else None
+            kappa = self._mmean(kap, m)
+        else:
+            kappa = torch.tensor(0.0)
+        if L >= 5:
+            dih = self._dihedral(a)
+            tv = (dih[:, 1:] - dih[:, :-1]).pow(2).sum(-1)
+            m = ((mask[:, 4:] & mask[:, 3:-1] & mask[:, 2:-2] & mask[:, 1:-3] & mask[:, :-4])
+                 if mask is not None else None)
+            tau = self._mmean(tv, m)
+        else:
+            tau = torch.tensor(0.0)
+        return kappa, tau
+
+    def _long_range_pdm(self, a, b, mask, min_sep, stride, max_offsets):
+        L = a.shape[1]
+        if L < min_sep + 1:
+            return torch.tensor(0.0)
+        tot, n = 0.0, 0
+        for off in range(0, max(1, max_offsets)):
+            for i in range(0, L, max(1, stride)):
+                j = i + min_sep + off
+                if j >= L:
+                    break
+                da = (a[:, j] - a[:, i]).norm(dim=-1)
+                db = (b[:, j] - b[:, i]).norm(dim=-1)
+                m = (mask[:, j] & mask[:, i]) if mask is not None else None
+                tot = tot + self._mmean((da - db).pow(2), m)
+                n += 1
+        return torch.tensor(0.0) if n == 0 else tot / float(n)
+
+    def loss_function(self, recons, target, vq_pack, mask=None, **kw):
+        c = self.cfg
+        zq, ze, _idx, ppl, dead = vq_pack
+        g = lambda k, d: float(kw.get(k, d))
+        ss_w, rmsd_w = g("ss_weight", 1.0), g("rmsd_weight", 1.0)
+        bl_w, ba_w = g("bond_length_weight", 0.0), g("bond_angle_weight", 0.0)
+        tv_l, dir_w, dih_w = g("xyz_tv_lambda", 0.0), g("dir_weight", 0.0), g("dih_weight", 0.0)
+        pdm_w, wk_w = g("pdm_weight", 0.0), g("win_kabsch_weight", 0.0)
+        kap_w, tau_w, lr_w = g("kappa_weight", 0.0), g("tau_weight", 0.0), g("lr_pdm_weight", 0.0)
+        pdm_window = int(kw.get("pdm_window", 8))
+        wk_size, wk_stride = int(kw.get("win_kabsch_size", 16)), int(kw.get("win_kabsch_stride", 8))
+        lr_sep, lr_stride, lr_max = (int(kw.get("lr_min_sep", 24)), int(kw.get("lr_stride", 8)),
+                                     int(kw.get("lr_max_offsets", 8)))
+        alpha = float(c["xyz_align_alpha"])
+        ss_tv_l = float(c["ss_tv_lambda"])
+
+        rx, rlog = recons[..., :3], recons[..., 3:]
+        gx, g1h = target[..., :3], target[..., 3:]
+        L = rx.shape[1]
+
+        # xyz: raw vs Kabsch-aligned per-sample MSE (:1130-1172)
+        raw_ps = self._per_sample_mse(rx, gx, mask)
+        l_raw = raw_ps.mean()
+        aln_ps, best_ps, l_aln = raw_ps, raw_ps, l_raw
+        can = L >= 3
+        if can and mask is not None:
+            can = bool((mask.sum(1) >= 3).any())
+        if can:
+            R, t, ok = self.kabsch(rx, gx, mask)
+            if bool(ok.any()):
+                aln_ps = self._per_sample_mse(rx @ R + t, gx, mask)
+                sel = ok if mask is None else (ok & (mask.sum(1) >= 3))
+                best_ps = torch.where(sel, torch.minimum(raw_ps, aln_ps), raw_ps)
+                l_aln = best_ps.mean()
+        l_xyz = alpha * l_aln + (1.0 - alpha) * l_raw
+        with torch.no_grad():
+            rmsd_raw = raw_ps.clamp_min(1e-12).sqrt().mean()
+            rmsd_aln = best_ps.clamp_min(1e-12).sqrt().mean()
+
+        # secondary-structure CE (:1184-1200)
+        lab = g1h.argmax(-1)
+        logp = torch.log_softmax(rlog, dim=-1)
+        if self.label_smoothing and self.label_smoothing > 0.0:
+            eps, C = self.label_smoothing, rlog.shape[-1]
+            tgt = torch.full_like(rlog, eps / (C - 1)).scatter_(-1, lab[..., None], 1.0 - eps)
+            per = (tgt * (tgt.log() - logp)).sum(-1)          # F.kl_div(logp, tgt).sum(-1)
+        else:
+            per = -logp.gather(-1, lab[..., None])[..., 0]
+        l_ss = self._mmean(per, mask)
+
+        # SS total variation (:1203-1215)
+        if ss_tv_l > 0.0 and L >= 2:
+            p = torch.softmax(rlog, -1)
+            tvv = (p[:, 1:] - p[:, :-1]).abs().sum(-1)
+            ss_tv = self._mmean(tvv, (mask[:, 1:] & mask[:, :-1]) if mask is not None else None)
+        else:
+            ss_tv = torch.tensor(0.0)
+
+        def real(v):                                              # :1218-1227
+            if self.data_std is not None:
+                return v * self.data_std + (self.data_mean if self.data_mean is not None else 0.0)
+            return v
+        ra, ga = real(rx), real(gx)
+        pair = (mask[:, 1:] & mask[:, :-1]) if mask is not None else None
+        tri = (mask[:, 2:] & mask[:, 1:-1] & mask[:, :-2]) if mask is not None else None
+
+        if L >= 2:                                                # bond length :1230-1241
+            rl = (ra[:, 1:] - ra[:, :-1]).norm(dim=-1)
+            gl = (ga[:, 1:] - ga[:, :-1]).norm(dim=-1)
+            bl = self._mmean((rl - gl) ** 2, pair)
+        else:
+            bl = torch.tensor(0.0)
+        if L >= 3:                                                # bond angle :1244-1261
+            cosang = lambda v: (unit(v[:, 1:-1] - v[:, :-2]) * unit(v[:, 2:] - v[:, 1:-1])).sum(-1)
+            ba = self._mmean((cosang(ra) - cosang(ga)) ** 2, tri)
+        else:
+            ba = torch.tensor(0.0)
+        if L >= 2:                                                # direction :1264-1275
+            cu = (unit(ra[:, 1:] - ra[:, :-1]) * unit(ga[:, 1:] - ga[:, :-1])).sum(-1)
+            dirl = self._mmean(1.0 - cu, pair)
+        else:
+            dirl = torch.tensor(0.0)
+        if L >= 4:                                                # dihedral :1278-1287
+            dd = (self._dihedral(ra) - self._dihedral(ga)).pow(2)
+            if mask is not None:
+                qm = mask[:, 3:] & mask[:, 2:-1] & mask[:, 1:-2] & mask[:, :-3]
+                dih = self._mmean(dd.sum(-1), qm)
+            else:
+                dih = dd.mean()                                   # mean over [B,L-3,2]
+        else:
+            dih = torch.tensor(0.0)
+        geom = bl_w * bl + ba_w * ba + dir_w * dirl + dih_w * dih
+
+        if self.use_vq:                                           # commitment :1292-1296
+            vq_loss = self.beta * ((zq.detach() - ze) ** 2).mean()
+        else:
+            vq_loss = torch.tensor(0.0)
+
+        usage_reg = torch.tensor(0.0)                             # :1299-1309
+        if self.usage_entropy_lambda > 0.0 and ze.numel() > 0 and self.use_vq:
+            pc = torch.softmax(ze.reshape(-1, ze.shape[-1]) @ self.sd["quantizer.embedding"].detach().t(),
+                               dim=-1).mean(0)
+            usage_reg = self.usage_entropy_lambda * (pc * pc.clamp_min(1e-12).log()).sum()
+
+        if tv_l > 0.0 and L >= 3:                                 # xyz TV2 :1312-1322
+            d1 = rx[:, 1:] - rx[:, :-1]
+            xyz_tv = self._mmean((d1[:, 1:] - d1[:, :-1]).pow(2).sum(-1), tri)
+        else:
+            xyz_tv = torch.tensor(0.0)
+
+        z0 = torch.tensor(0.0)
+        pdm = self._local_pdm(ra, ga, mask, pdm_window) if pdm_w > 0 else z0
+        wkl = self._window_kabsch(ra, ga, mask, wk_size, wk_stride) if wk_w > 0 else z0
+        kap, tau = self._frenet(ra, mask)
+        kap = kap if kap_w > 0 else z0
+        tau = tau if tau_w > 0 else z0
+        lrp = self._long_range_pdm(ra, ga, mask, lr_sep, lr_stride, lr_max) if lr_w > 0 else z0
+
+        total = (rmsd_w * l_xyz + ss_w * l_ss + vq_loss + geom + ss_tv_l * ss_tv + usage_reg
+                 + tv_l * xyz_tv + pdm_w * pdm + wk_w * wkl + kap_w * kap + tau_w * tau + lr_w * lrp)
+
+        with torch.no_grad():
+            hit = rlog.argmax(-1) == lab
+            if mask is not None:
+                acc = (hit & mask).sum().float() / mask.sum().float().clamp_min(1.0)
+            else:
+                acc = hit.float().mean()
+        out = {
+            "loss": total,
+            "Reconstruction_Loss_XYZ": l_xyz.detach(), "XYZ_MSE_Raw": l_raw.detach(),
+            "XYZ_MSE_Aligned": aln_ps.mean().detach(), "Reconstruction_Loss_SS": l_ss.detach(),
+            "SS_Accuracy": acc, "VQ_Loss": vq_loss.detach(),
+            "Geom_BondLength_Loss": bl.detach(), "Geom_BondAngle_Loss": ba.detach(),
+            "Geom_Direction_Loss": dirl.detach(), "Geom_Dihedral_Loss": dih.detach(),
+            "Geom_Loss": torch.as_tensor(geom).detach(), "SS_TV": ss_tv.detach(),
+            "Usage_Reg": usage_reg.detach(), "XYZ_TV2": xyz_tv.detach(),
+            "VQ_Perplexity": ppl.detach(), "VQ_DeadRatio": dead.detach(),
+            "RMSD_Raw": rmsd_raw, "RMSD_Aligned": rmsd_aln,
+        }
+        if pdm_w > 0:
+            out["Geom_LocalPDM"] = pdm.detach()
+        if wk_w > 0:
+            out["Geom_WinKabsch"] = wkl.detach()
+        if kap_w > 0:
+            out["Frenet_Kappa"] = kap.detach()
+        if tau_w > 0:
+            out["Frenet_Tau"] = tau.detach()
+        if lr_w > 0:
+            out["Geom_LongRangePDM"] = lrp.detach()
+        return out
+
+    # ---- one training step (experiment.py:351-476 + Lightning: backward, clip, AdamW) --------
+    def params(self):
+        return [self.sd[k] for k in param_shapes(self.cfg)]
+
+    def train_step(self, x, mask, opt, clip, weights):
+        for p in self.params():
+            p.grad = None
+        out = self.forward(x, mask)
+        ld = self.loss_function(out[0], out[1], out[2], out[3], **weights)
+        ld["loss"].backward()
+        gn = torch.nn.utils.clip_grad_norm_(self.params(), clip) if clip and clip > 0 else None
+        opt.step()
+        return ld, out, gn
+
+
+def attach_grads(sd, cfg):
+    """Make every trainable tensor a leaf that records gradients."""
+    for k in param_shapes(cfg):
+        sd[k] = sd[k].detach().clone().requires_grad_(True)
+    return sd
