@@ -1,0 +1,133 @@
+/*
+ * vqvae_hip.h -- C ABI of libvqvae_hip.so: the MI355X (gfx950) kernels of the VQ-VAE training step.
+ *
+ * The reference (jluuser/PyTorch-VAE) has no FFI of its own: its hot path is Python calling torch ops.
+ * Each entry point below replaces the torch call(s) cited next to it (paths relative to the reference
+ * root); INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted
+ *   - row-major fp32 tensors with explicit leading dimensions (ld*, in elements)
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no hidden synchronisation, no
+ *     allocation, no ownership transfer: the caller owns every buffer including `workspace`
+ *   - returns 0 on success, <0 on error; vqh_last_error() returns a thread-local message
+ *   - safe to capture into a hipGraph (all step-varying scalars are read from device memory)
+ *   - dropout masks are Philox4x32-10 functions of (seed, step, site, element): rng_state points to
+ *     two device uint64 {seed, step}; backward regenerates the forward mask from the same site id
+ */
+#ifndef VQVAE_HIP_H
+#define VQVAE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vqh_stream_t; /* hipStream_t */
+
+const char* vqh_last_error(void);
+int vqh_abi_version(void);
+
+/* rng_state[1] += 1  (once per training step) */
+int vqh_rng_advance(unsigned long long* rng_state, vqh_stream_t stream);
+int vqh_memset(void* ptr, int value, long long bytes, vqh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM:  C[M,N] = epilogue( opA(A)[M,K] . opB(B)[K,N] ) (+ beta*C)
+ *   a_kcontig=1: A stored [M,K] (lda>=K)   a_kcontig=0: A stored [K,M] (lda>=M)
+ *   b_kcontig=1: B stored [N,K] (ldb>=K)   b_kcontig=0: B stored [K,N] (ldb>=N)
+ * replaces: every nn.Linear / MultiheadAttention projection forward (models/vq_vae.py:455-533),
+ *           and their autograd dgrad / wgrad products.
+ * epilogue modes (bias may be NULL):
+ *   0 LINEAR       v = acc + bias
+ *   1 RELU_DROP    v = dropout(relu(acc + bias))                  TransformerEncoderLayer._ff_block
+ *   2 GELU         aux_out = acc + bias ; v = gelu_erf(aux_out)   tokenizer ffn / fuse_mlp (:302-306, :497-502)
+ *   3 DROP_RESID   v = aux_in + dropout(acc + bias)               residual adds (x = x + dropout(...))
+ *   4 SIGMOID      v = sigmoid(acc + bias)                        latent_sigmoid (:740-742)
+ *   5 MUL_POSMASK  v = acc * (aux_in > 0 ? 1/(1-p) : 0)           backward of mode 1 through its saved output
+ *   6 MUL_GELUGRAD v = acc * gelu'(aux_in)                        backward of mode 2
+ *   7 MUL_SIGGRAD  v = acc * aux_in * (1 - aux_in)
+ * workspace (may be NULL): split-K slabs; used automatically when the output has < 256 tiles.
+ * ------------------------------------------------------------------------------------------- */
+int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+             float* C, int ldc, const float* bias, int mode, const float* aux_in, float* aux_out, int ldaux,
+             float beta, const unsigned long long* rng_state, unsigned drop_site, float drop_p, float* workspace,
+             long long workspace_floats, vqh_stream_t stream);
+
+/* nn.LayerNorm forward/backward (eps 1e-5, biased variance); 35 instances on the path */
+int vqh_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, float* mean,
+                      float* rstd, int rows, int H, float eps, vqh_stream_t stream);
+int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
+                      const float* rstd, float* dx, int lddx, int accumulate_dx, float* dw, float* db, float beta,
+                      int rows, int H, float* workspace, long long workspace_floats, vqh_stream_t stream);
+
+/* out[i] = beta*out[i] + sum_s slabs[s*stride + i] ;  out[n] = beta*out[n] + sum_m X[m][n] */
+int vqh_reduce_slabs(const float* slabs, int S, long long stride, long long n, float* out, float beta,
+                     vqh_stream_t stream);
+int vqh_colsum(const float* X, int ld, int M, int N, float* out, float beta, float* workspace,
+               long long workspace_floats, vqh_stream_t stream);
+
+/* input_proj / ss_input_proj + inp_dropout + pos_enc (models/vq_vae.py:642-643, 649-650) and its weight grads */
+int vqh_embed_fwd(const float* x, int ldx, int col0, const float* W, const float* b, const float* pe, float* out,
+                  int rows, int L, int H, const unsigned long long* rng_state, unsigned drop_site, float drop_p,
+                  vqh_stream_t stream);
+int vqh_embed_bwd(const float* dy, const float* x, int ldx, int col0, float* dW, float* db, float beta, int rows,
+                  int H, const unsigned long long* rng_state, unsigned drop_site, float drop_p, float* workspace,
+                  long long workspace_floats, vqh_stream_t stream);
+
+/* out[b,:] = p0 (+ p1): tokenizer.queries expand (:313), query_embed[:L] + pos_enc[:L] (:750-751) */
+int vqh_bcast_rows(const float* p0, const float* p1, float* out, int B, long long n, vqh_stream_t stream);
+int vqh_dropout_bwd(const float* dy, float* out, long long n, const unsigned long long* rng_state,
+                    unsigned drop_site, float drop_p, vqh_stream_t stream);
+int vqh_add(const float* a, const float* b, float* out, long long n, vqh_stream_t stream);
+int vqh_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, vqh_stream_t stream);
+int vqh_sigmoid_bwd(const float* dy, const float* y, float* out, long long n, vqh_stream_t stream);
+
+/* nn.MultiheadAttention core (scaled scores, key padding mask, softmax, dropout, P.V), flash style.
+ * Q/K/V/O element (b, t, head, d) at ptr[(b*T + t)*ld + head*dh + d]; kvalid [B,S] bytes (1 = attend) or NULL. */
+int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                 float* LSE, const unsigned char* kvalid, int B, int nh, int T, int S, int dh,
+                 const unsigned long long* rng_state, unsigned drop_site, float drop_p, vqh_stream_t stream);
+int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                 const float* LSE, const float* dO, int lddo, float* Dsum, float* dQ, int lddq, float* dK, int lddk,
+                 float* dV, int lddv, const unsigned char* kvalid, int B, int nh, int T, int S, int dh,
+                 const unsigned long long* rng_state, unsigned drop_site, float drop_p, vqh_stream_t stream);
+
+/* VectorQuantizerEMA (models/vq_vae.py:19-283) */
+int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
+                   int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);
+int vqh_vq_gather(const float* E, int lde, const long long* idx, int idx_offset, const float* rows_in, int ldr,
+                  float* zq_level, float* res_out, int R, int D, vqh_stream_t stream);
+int vqh_vq_finish(const float* zq_levels, int Q, const float* ze, int ldz, float* zq, float* zst, int R, int D,
+                  vqh_stream_t stream);
+int vqh_vq_segment_sum(const float* rows, int ldr, const long long* idx, int R, int D, int k0, int Kn, float* cnt,
+                       float* sum, vqh_stream_t stream);
+int vqh_vq_ema_apply(const float* cnt, const float* sum, float* ema_cnt, float* ema_emb, float* emb, int K, int D,
+                     float decay, float one_minus_decay, float eps, vqh_stream_t stream);
+int vqh_vq_usage_stats(const float* usage, int K, float n_positions, float* ep_usage, float* ep_cnt, float* stats,
+                       vqh_stream_t stream);
+
+/* VQVAE.loss_function forward + gradient w.r.t. recons / z_e (models/vq_vae.py:1097-1388).
+ * weights[16] = {rmsd_w, ss_w, bond_length_w, bond_angle_w, dir_w, dih_w, xyz_tv_lambda, pdm_w, win_kabsch_w,
+ *                kappa_w, tau_w, lr_pdm_w, xyz_align_alpha, ss_tv_lambda, label_smoothing, beta}   (HOST pointer)
+ * iparams[6]  = {pdm_window, win_kabsch_size, win_kabsch_stride, lr_min_sep, lr_stride, lr_max_offsets} (HOST)
+ * metrics[24] (device): loss, Reconstruction_Loss_XYZ, XYZ_MSE_Raw, XYZ_MSE_Aligned, Reconstruction_Loss_SS,
+ *   SS_Accuracy, VQ_Loss, Geom_BondLength_Loss, Geom_BondAngle_Loss, Geom_Direction_Loss, Geom_Dihedral_Loss,
+ *   Geom_Loss, SS_TV, Usage_Reg, XYZ_TV2, VQ_Perplexity, VQ_DeadRatio, RMSD_Raw, RMSD_Aligned, Geom_LocalPDM,
+ *   Geom_WinKabsch, Frenet_Kappa, Frenet_Tau, Geom_LongRangePDM */
+int vqh_loss_fwd_bwd(const float* recons, const float* target, const unsigned char* mask, int masked, const float* ze,
+                     const float* zq, const float* vq_stats, int B, int L, int Ntok, int D, int use_vq,
+                     const float* weights, const int* iparams, float* d_recons, float* d_ze, float* metrics,
+                     float* workspace, long long workspace_floats, vqh_stream_t stream);
+
+/* clip_grad_norm_ + torch.optim.AdamW over flat buffers (experiment.py:170, run.py:191-197).
+ * hyper (device floats): lr, beta1, beta2, eps, weight_decay, max_norm, 1-beta1^t, 1-beta2^t
+ * norm_out (device, 2 floats): total grad norm, clip coefficient */
+int vqh_grad_norm(const float* g, long long n, const float* hyper, float* norm_out, double* workspace,
+                  vqh_stream_t stream);
+int vqh_adamw_step(float* p, float* g, float* m, float* v, long long n, const float* hyper, const float* norm,
+                   vqh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQVAE_HIP_H */

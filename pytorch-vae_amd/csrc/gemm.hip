@@ -1,0 +1,355 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, 155 TF/s chip peak).
+//
+//   C[M,N] = epilogue( opA(A)[M,K] . opB(B)[K,N] )
+//
+// One kernel template covers the three products of a Linear layer (reference call sites: every
+// nn.Linear / MHA projection of /root/reference/models/vq_vae.py:455-533):
+//   forward  Y  = X . W^T      : A k-contiguous [M,K], B k-contiguous [N,K]   (A_KC, B_KC)
+//   dgrad    dX = dY . W       : A k-contiguous [M,K], B stored [K,N]          (A_KC, !B_KC)
+//   wgrad    dW = dY^T . X     : A stored [K,M],       B stored [K,N]          (!A_KC, !B_KC), split-K
+//
+// Block = 256 threads = 4 waves (2x2), tile 128x128x32, each wave 64x64 = 2x2 MFMA tiles of 32x32.
+// Operand tiles are staged global -> registers -> LDS (double buffered, one barrier per K-step; the
+// next tile's global loads are issued before the MFMA block so HBM/L2 latency hides under it).
+// LDS images:
+//   k-contiguous source : [row][BK+4] floats; a lane reads 4 consecutive k with one ds_read_b128
+//                         (row stride 36 dwords => the 16-lane groups of ds_read_b128 hit 64
+//                         distinct banks); lane half h owns k = 8t+4h+j, the same permutation of
+//                         the reduction index is used for A and B so the sum is unchanged.
+//   row-contiguous source: [k][rows] floats; a lane reads [8t+4h+j][row0 + lane&31] with
+//                         ds_read_b32 (32 consecutive dwords per half: conflict free).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KC_LD = BK + 4;            // padded row of a k-contiguous LDS image
+constexpr int A_TILE = BM * KC_LD;       // floats per operand tile buffer (upper bound of both layouts)
+
+enum EpiMode {
+    EPI_LINEAR = 0,        // v = acc + bias
+    EPI_RELU_DROP = 1,     // v = dropout(relu(acc + bias))
+    EPI_GELU = 2,          // aux_out = acc + bias ; v = gelu(aux_out)
+    EPI_DROP_RESID = 3,    // v = aux_in + dropout(acc + bias)
+    EPI_SIGMOID = 4,       // v = sigmoid(acc + bias)
+    EPI_MUL_POSMASK = 5,   // v = acc * (aux_in > 0 ? drop.scale : 0)      (relu+dropout backward)
+    EPI_MUL_GELUGRAD = 6,  // v = acc * gelu'(aux_in)
+    EPI_MUL_SIGGRAD = 7,   // v = acc * aux_in * (1 - aux_in)
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int kchunk;            // K range handled by one blockIdx.z (multiple of BK)
+    int vecA, vecB;        // 16-byte vector loads legal for this operand
+    float* ws;             // split-K slabs [gridDim.z][M][N] (raw partial sums) or null
+    // epilogue
+    int mode;
+    const float* bias;
+    const float* aux_in;
+    float* aux_out;
+    int ldaux;
+    float beta;
+    DropCfg drop;
+};
+
+__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float acc, int row, int col,
+                                                unsigned long long seed, unsigned long long step) {
+    float v = acc;
+    if (g.mode <= EPI_SIGMOID) {
+        if (g.bias) v += g.bias[col];
+        switch (g.mode) {
+            case EPI_RELU_DROP:
+                v = fmaxf(v, 0.f);
+                if (g.drop.p > 0.f) v *= drop1(g.drop, seed, step, (unsigned long long)row * g.N + col);
+                break;
+            case EPI_GELU:
+                g.aux_out[(size_t)row * g.ldaux + col] = v;
+                v = gelu_erf(v);
+                break;
+            case EPI_DROP_RESID:
+                if (g.drop.p > 0.f) v *= drop1(g.drop, seed, step, (unsigned long long)row * g.N + col);
+                v += g.aux_in[(size_t)row * g.ldaux + col];
+                break;
+            case EPI_SIGMOID:
+                v = 1.f / (1.f + __expf(-v));
+                break;
+            default:
+                break;
+        }
+    } else {
+        const float a = g.aux_in[(size_t)row * g.ldaux + col];
+        if (g.mode == EPI_MUL_POSMASK) v = (a > 0.f) ? v * g.drop.scale : 0.f;
+        else if (g.mode == EPI_MUL_GELUGRAD) v *= gelu_erf_grad(a);
+        else v *= a * (1.f - a);
+    }
+    return v;
+}
+
+// Load this thread's share (4 x float4) of one operand tile into registers.
+//   KC  : tile element (r, k) lives at src[(row0 + r) * ld + k]
+//   !KC : tile element (r, k) lives at src[k * ld + row0 + r]
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int rows, int row0, int k0,
+                                          int kend, bool vec, int tid, f32x4 (&regs)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (KC) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            const int k = k0 + (tid & 7) * 4;
+            if (r < rows) {
+                const float* p = src + (size_t)r * ld + k;
+                if (vec && k + 3 < kend) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < kend) v[e] = p[e];
+                }
+            }
+        } else {
+            const int k = k0 + (tid >> 5) + 8 * i;
+            const int r = row0 + (tid & 31) * 4;
+            if (k < kend) {
+                const float* p = src + (size_t)k * ld + r;
+                if (vec && r + 3 < rows) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (r + e < rows) v[e] = p[e];
+                }
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const f32x4 (&regs)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (KC) {
+            const int r = (tid >> 3) + 32 * i;
+            *reinterpret_cast<f32x4*>(lds + r * KC_LD + (tid & 7) * 4) = regs[i];
+        } else {
+            const int k = (tid >> 5) + 8 * i;
+            *reinterpret_cast<f32x4*>(lds + k * BM + (tid & 31) * 4) = regs[i];
+        }
+    }
+}
+
+// Fragment for MFMA group t (k = 8t .. 8t+7): 4 values per lane, value j belongs to k = 8t + 4h + j.
+template <bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int row, int t, int h) {
+    if (KC) {
+        return *reinterpret_cast<const f32x4*>(lds + row * KC_LD + 8 * t + 4 * h);
+    } else {
+        f32x4 v;
+        const float* p = lds + (8 * t + 4 * h) * BM + row;
+        v[0] = p[0];
+        v[1] = p[BM];
+        v[2] = p[2 * BM];
+        v[3] = p[3 * BM];
+        return v;
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // stage s: A tile at smem + 2*s*A_TILE, B tile right behind it
+#define AS(s) (smem + (s) * 2 * A_TILE)
+#define BS(s) (smem + (s) * 2 * A_TILE + A_TILE)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<A_KC>(g.A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
+        load_tile<B_KC>(g.B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
+        store_tile<A_KC>(AS(0), tid, ra);
+        store_tile<B_KC>(BS(0), tid, rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_tile<A_KC>(g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BK, kend, g.vecA, tid, ra);
+            load_tile<B_KC>(g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BK, kend, g.vecB, tid, rb);
+        }
+        const float* a_s = AS(cur);
+        const float* b_s = BS(cur);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_KC>(a_s, wm * 64 + i * 32 + l31, t, h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_KC>(b_s, wn * 64 + j * 32 + l31, t, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<A_KC>(AS(cur ^ 1), tid, ra);
+            store_tile<B_KC>(BS(cur ^ 1), tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*h of each 32x32 tile ----
+    unsigned long long seed = 0, step = 0;
+    if (g.drop.p > 0.f && g.drop.rng_state) {
+        seed = g.drop.rng_state[0];
+        step = g.drop.rng_state[1];
+    }
+    float* slab = g.ws ? g.ws + (size_t)blockIdx.z * g.M * g.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= g.M) continue;
+                if (slab) {
+                    slab[(size_t)row * g.N + col] = acc[i][j][r];
+                } else {
+                    float v = epilogue_value(g, acc[i][j][r], row, col, seed, step);
+                    float* c = g.C + (size_t)row * g.ldc + col;
+                    if (g.beta != 0.f) v += g.beta * (*c);
+                    *c = v;
+                }
+            }
+        }
+}
+
+// Sum split-K slabs, add bias, C = beta*C + sum.  One thread per 4 consecutive columns.
+__global__ void splitk_reduce(const float* __restrict__ ws, int S, int M, int N, float* __restrict__ C, int ldc,
+                              const float* __restrict__ bias, float beta) {
+    const size_t total = (size_t)M * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += ws[(size_t)z * total + e];
+        const int row = (int)(e / N), col = (int)(e % N);
+        if (bias) s += bias[col];
+        float* c = C + (size_t)row * ldc + col;
+        if (beta != 0.f) s += beta * (*c);
+        *c = s;
+    }
+}
+
+template <bool A_KC, bool B_KC>
+int launch(const GemmArgs& g, int splits, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t smem = (size_t)4 * A_TILE * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<A_KC, B_KC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            vqh_set_error(hipGetErrorString(e));
+            return VQH_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, splits);
+    hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC>), grid, dim3(256), smem, stream, g);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+}  // namespace
+
+// C-ABI: see include/vqvae_hip.h for the contract.
+extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B,
+                        int ldb, float* C, int ldc, const float* bias, int mode, const float* aux_in, float* aux_out,
+                        int ldaux, float beta, const unsigned long long* rng_state, unsigned drop_site, float drop_p,
+                        float* workspace, long long workspace_floats, hipStream_t stream) {
+    VQH_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "vqh_gemm: negative dimension");
+    if (M == 0 || N == 0) return VQH_OK;
+    VQH_CHECK_ARG(C && ((A && B) || K == 0), "vqh_gemm: null operand");
+    VQH_CHECK_ARG(mode >= EPI_LINEAR && mode <= EPI_MUL_SIGGRAD, "vqh_gemm: unknown epilogue mode");
+    VQH_CHECK_ARG(lda >= (a_kcontig ? K : M) && ldb >= (b_kcontig ? K : N) && ldc >= N, "vqh_gemm: leading dim too small");
+    if (mode == EPI_GELU) VQH_CHECK_ARG(aux_out && ldaux >= N, "vqh_gemm: GELU epilogue needs aux_out");
+    if (mode == EPI_DROP_RESID || mode >= EPI_MUL_POSMASK)
+        VQH_CHECK_ARG(aux_in && ldaux >= N, "vqh_gemm: epilogue needs aux_in");
+    VQH_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "vqh_gemm: dropout p out of range");
+    if (drop_p > 0.f && (mode == EPI_RELU_DROP || mode == EPI_DROP_RESID))
+        VQH_CHECK_ARG(rng_state != nullptr, "vqh_gemm: dropout needs rng_state");
+
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+    g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+    g.mode = mode; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.beta = beta;
+    g.drop.rng_state = rng_state; g.drop.site = drop_site; g.drop.p = drop_p; g.drop.scale = 1.f / (1.f - drop_p);
+    g.ws = nullptr;
+
+    // split-K when the output has too few tiles to fill 256 CUs (weight gradients: K = B*L rows).
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int splits = 1;
+    if (workspace && mode == EPI_LINEAR && tiles < 256 && K >= 8 * BK) {
+        splits = (512 + tiles - 1) / tiles;
+        const int max_by_k = K / (4 * BK);
+        if (splits > max_by_k) splits = max_by_k;
+        const long long per = (long long)M * N;
+        if ((long long)splits * per > workspace_floats) splits = (int)(workspace_floats / per);
+        if (splits < 2) splits = 1;
+    }
+    int kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    if (kchunk <= 0) kchunk = BK;
+    splits = (K + kchunk - 1) / kchunk;
+    if (splits < 1) splits = 1;
+    g.kchunk = kchunk;
+    if (splits > 1) g.ws = workspace;
+
+    int rc;
+    if (a_kcontig && b_kcontig) rc = launch<true, true>(g, splits, stream);
+    else if (a_kcontig && !b_kcontig) rc = launch<true, false>(g, splits, stream);
+    else if (!a_kcontig && b_kcontig) rc = launch<false, true>(g, splits, stream);
+    else rc = launch<false, false>(g, splits, stream);
+    if (rc != VQH_OK) return rc;
+    if (splits > 1) {
+        const size_t total = (size_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, stream, workspace, splits, M, N, C, ldc, bias, beta);
+        VQH_LAUNCH_CHECK();
+    }
+    return VQH_OK;
+}

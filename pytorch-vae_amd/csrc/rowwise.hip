@@ -1,0 +1,428 @@
+// HBM-bound row-wise kernels of the training step: LayerNorm forward/backward, the 3->H input
+// embeddings (+dropout +positional table), broadcast parameters, column sums (bias gradients),
+// dropout backward.  One wave (64 lanes) per row, float4 accesses when the row pitch allows it.
+// Reference call sites: nn.LayerNorm instances /root/reference/models/vq_vae.py:462-465,501,524 and the
+// per-layer norms; input_proj/ss_input_proj + pos_enc :642-650; query_embed + pos_enc :750-751.
+#include "common.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * w + b ; saves mean / rstd per row for backward.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ y, int ldy, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int rows, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int i = lane; i < H; i += 64) s += xr[i];
+    const float mu = wave_sum(s) / (float)H;
+    float v = 0.f;
+    for (int i = lane; i < H; i += 64) {
+        const float d = xr[i] - mu;
+        v += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(v) / (float)H + eps);
+    float* yr = y + (size_t)row * ldy;
+    for (int i = lane; i < H; i += 64) yr[i] = (xr[i] - mu) * rs * w[i] + b[i];
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward.  dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * w.
+// Each wave walks rows (grid-stride) and keeps dw/db partial sums for its columns in registers;
+// the 4 waves of a block are combined through LDS and written as one slab per block:
+//   part[block][0][H] = sum dy*xhat ,  part[block][1][H] = sum dy
+// (summed by vqh_reduce_slabs: deterministic, no atomics).
+// ------------------------------------------------------------------------------------------
+template <int VPT>  // values per lane: H <= 64*VPT
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy,
+                                                            const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            int lddx, int accumulate, float* __restrict__ part,
+                                                            int rows, int H) {
+    __shared__ float red[WAVES_PER_BLOCK][2][64 * VPT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float aw[VPT], ab[VPT], wv[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        aw[j] = 0.f;
+        ab[j] = 0.f;
+        const int i = lane + 64 * j;
+        wv[j] = (i < H) ? w[i] : 0.f;
+    }
+    const float invH = 1.f / (float)H;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wave; row < rows; row += gridDim.x * WAVES_PER_BLOCK) {
+        const float* dyr = dy + (size_t)row * lddy;
+        const float* xr = x + (size_t)row * ldx;
+        const float mu = mean[row], rs = rstd[row];
+        float g[VPT], xh[VPT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int i = lane + 64 * j;
+            float d = 0.f, xv = 0.f;
+            if (i < H) {
+                d = dyr[i];
+                xv = (xr[i] - mu) * rs;
+            }
+            xh[j] = xv;
+            g[j] = d * wv[j];
+            aw[j] += d * xv;
+            ab[j] += d;
+            s1 += g[j];
+            s2 += g[j] * xv;
+        }
+        s1 = wave_sum(s1) * invH;
+        s2 = wave_sum(s2) * invH;
+        float* dxr = dx + (size_t)row * lddx;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int i = lane + 64 * j;
+            if (i < H) {
+                const float v = rs * (g[j] - s1 - xh[j] * s2);
+                dxr[i] = accumulate ? dxr[i] + v : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        red[wave][0][lane + 64 * j] = aw[j];
+        red[wave][1][lane + 64 * j] = ab[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * H; i += 256) {
+        const int which = i / H, c = i % H;
+        float s = 0.f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < WAVES_PER_BLOCK; ++wv_) s += red[wv_][which][c];
+        part[((size_t)blockIdx.x * 2 + which) * H + c] = s;
+    }
+}
+
+// out[i] = beta*out[i] + sum_s slabs[s*stride + i]
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, long long stride, long long n,
+                                    float* __restrict__ out, float beta) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += slabs[(size_t)k * stride + i];
+        out[i] = (beta != 0.f) ? beta * out[i] + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums: part[blk][n] = sum over the block's rows of X[m][n]   (bias / broadcast-param grads)
+// block (64 columns x 4 row lanes); grid (ceil(N/64), row_blocks)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, int M, int N,
+                                                     float* __restrict__ part, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + ry; r < r1; r += 4) s += X[(size_t)r * ld + c];
+    red[ry][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ry == 0 && c < N)
+        part[(size_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------
+// input embedding: out[r,:] = dropout(W[:, 0:3] . x[r, c0:c0+3] + b) + pe[r % L, :]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ x, int ldx, int c0,
+                                                        const float* __restrict__ W, const float* __restrict__ b,
+                                                        const float* __restrict__ pe, float* __restrict__ out,
+                                                        int rows, int L, int H, DropCfg drop) {
+    unsigned long long seed = 0, step = 0;
+    if (drop.p > 0.f) {
+        seed = drop.rng_state[0];
+        step = drop.rng_state[1];
+    }
+    const long long total = (long long)rows * H;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / H), hcol = (int)(e % H);
+        const float* xr = x + (size_t)r * ldx + c0;
+        float v = b[hcol] + W[hcol * 3 + 0] * xr[0] + W[hcol * 3 + 1] * xr[1] + W[hcol * 3 + 2] * xr[2];
+        if (drop.p > 0.f) v *= drop1(drop, seed, step, (unsigned long long)e);
+        out[e] = v + pe[(size_t)(r % L) * H + hcol];
+    }
+}
+
+// embedding backward: part[blk][c][h] (c = 0..2 weight columns, c = 3 bias) over the block's rows
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        int ldx, int c0, float* __restrict__ part, int rows, int H,
+                                                        int rows_per_block, DropCfg drop) {
+    __shared__ float red[4][4][64];
+    unsigned long long seed = 0, step = 0;
+    if (drop.p > 0.f) {
+        seed = drop.rng_state[0];
+        step = drop.rng_state[1];
+    }
+    const int hcol = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (hcol < H)
+        for (int r = r0 + ry; r < r1; r += 4) {
+            float d = dy[(size_t)r * H + hcol];
+            if (drop.p > 0.f) d *= drop1(drop, seed, step, (unsigned long long)r * H + hcol);
+            const float* xr = x + (size_t)r * ldx + c0;
+            a0 += d * xr[0];
+            a1 += d * xr[1];
+            a2 += d * xr[2];
+            a3 += d;
+        }
+    const int l = threadIdx.x & 63;
+    red[ry][0][l] = a0; red[ry][1][l] = a1; red[ry][2][l] = a2; red[ry][3][l] = a3;
+    __syncthreads();
+    if (ry == 0 && hcol < H) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            part[((size_t)blockIdx.y * 4 + c) * H + hcol] = red[0][c][l] + red[1][c][l] + red[2][c][l] + red[3][c][l];
+    }
+}
+
+// out[b, i] = p0[i] (+ p1[i])   for b in [0,B): broadcast of a parameter block over the batch
+__global__ void bcast_rows_kernel(const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ out,
+                                  int B, long long n) {
+    const long long total = (long long)B * n;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e % n;
+        out[e] = p1 ? p0[i] + p1[i] : p0[i];
+    }
+}
+
+// out = dy * keep(site, elem)   (dropout backward; identical Philox stream as the forward site)
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ out, long long n, DropCfg drop) {
+    const unsigned long long seed = drop.rng_state[0], step = drop.rng_state[1];
+    const long long nq = (n + 3) / 4;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        float f[4];
+        drop4(drop, seed, step, (unsigned long long)q, f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long i = q * 4 + e;
+            if (i < n) out[i] = dy[i] * f[e];
+        }
+    }
+}
+
+// out = a + b (elementwise, float4 when possible)
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+// out = dy * y * (1 - y)   (sigmoid backward through its saved output)
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+
+// y = sigmoid(x) in place variant helpers are in the GEMM epilogue; strided copy for concat layouts:
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows, int cols) {
+    const long long total = (long long)rows * cols;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / cols), c = (int)(e % cols);
+        dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
+    }
+}
+
+// dW[h][c] = beta*dW + s[c][h] ; db[h] = beta*db + s[3][h]
+__global__ void embed_scatter_kernel(const float* __restrict__ s, float* __restrict__ dW, float* __restrict__ db,
+                                     float beta, int H) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    for (int c = 0; c < 3; ++c) {
+        const float v = s[c * H + h];
+        dW[h * 3 + c] = (beta != 0.f) ? beta * dW[h * 3 + c] + v : v;
+    }
+    const float v = s[3 * H + h];
+    db[h] = (beta != 0.f) ? beta * db[h] + v : v;
+}
+
+inline int blocks_for(long long n, int per_block = 256, int cap = 4096) {
+    long long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int vqh_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
+                                 float* mean, float* rstd, int rows, int H, float eps, hipStream_t stream) {
+    VQH_CHECK_ARG(rows >= 0 && H > 0 && ldx >= H && ldy >= H, "vqh_layernorm_fwd: bad shape");
+    if (rows == 0) return VQH_OK;
+    VQH_CHECK_ARG(x && w && b && y, "vqh_layernorm_fwd: null pointer");
+    const int grid = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, y, ldy, mean, rstd, rows, H, eps);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_reduce_slabs(const float* slabs, int S, long long stride, long long n, float* out, float beta,
+                                hipStream_t stream) {
+    VQH_CHECK_ARG(S >= 0 && n >= 0, "vqh_reduce_slabs: bad shape");
+    if (n == 0) return VQH_OK;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, slabs, S, stride, n, out, beta);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+// dw/db are written as beta*old + sum (beta=0 overwrite).  workspace >= 2*H*nblocks floats.
+extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* w,
+                                 const float* mean, const float* rstd, float* dx, int lddx, int accumulate_dx,
+                                 float* dw, float* db, float beta, int rows, int H, float* workspace,
+                                 long long workspace_floats, hipStream_t stream) {
+    VQH_CHECK_ARG(rows >= 0 && H > 0 && H <= 2048, "vqh_layernorm_bwd: H must be in [1,2048]");
+    if (rows == 0) return VQH_OK;
+    VQH_CHECK_ARG(dy && x && w && mean && rstd && dx && dw && db && workspace, "vqh_layernorm_bwd: null pointer");
+    int nblk = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (nblk > 512) nblk = 512;
+    VQH_CHECK_ARG((long long)nblk * 2 * H <= workspace_floats, "vqh_layernorm_bwd: workspace too small");
+#define LN_BWD(V)                                                                                                  \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<V>), dim3(nblk), dim3(256), 0, stream, dy, lddy, x, ldx, w, mean, rstd, \
+                       dx, lddx, accumulate_dx, workspace, rows, H)
+    if (H <= 64) LN_BWD(1);
+    else if (H <= 128) LN_BWD(2);
+    else if (H <= 256) LN_BWD(4);
+    else if (H <= 512) LN_BWD(8);
+    else if (H <= 1024) LN_BWD(16);
+    else LN_BWD(32);
+#undef LN_BWD
+    VQH_LAUNCH_CHECK();
+    // slab layout [blk][2][H]: dw = sum_blk slab[blk][0], db = sum_blk slab[blk][1]
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(H)), dim3(256), 0, stream, workspace, nblk, (long long)2 * H,
+                       (long long)H, dw, beta);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(H)), dim3(256), 0, stream, workspace + H, nblk,
+                       (long long)2 * H, (long long)H, db, beta);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+// out[n] = beta*out[n] + sum_m X[m][n]
+extern "C" int vqh_colsum(const float* X, int ld, int M, int N, float* out, float beta, float* workspace,
+                          long long workspace_floats, hipStream_t stream) {
+    VQH_CHECK_ARG(M >= 0 && N >= 0 && ld >= N, "vqh_colsum: bad shape");
+    if (N == 0) return VQH_OK;
+    VQH_CHECK_ARG(out && workspace, "vqh_colsum: null pointer");
+    int rb = (M + 255) / 256;
+    if (rb < 1) rb = 1;
+    if (rb > 128) rb = 128;
+    const int rows_per_block = (M + rb - 1) / rb > 0 ? (M + rb - 1) / rb : 1;
+    VQH_CHECK_ARG((long long)rb * N <= workspace_floats, "vqh_colsum: workspace too small");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, rb), dim3(256), 0, stream, X, ld, M, N, workspace, rows_per_block);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(N)), dim3(256), 0, stream, workspace, rb, (long long)N,
+                       (long long)N, out, beta);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_embed_fwd(const float* x, int ldx, int col0, const float* W, const float* b, const float* pe,
+                             float* out, int rows, int L, int H, const unsigned long long* rng_state,
+                             unsigned drop_site, float drop_p, hipStream_t stream) {
+    VQH_CHECK_ARG(rows >= 0 && L > 0 && H > 0 && ldx >= col0 + 3, "vqh_embed_fwd: bad shape");
+    if (rows == 0) return VQH_OK;
+    VQH_CHECK_ARG(x && W && b && pe && out, "vqh_embed_fwd: null pointer");
+    VQH_CHECK_ARG(drop_p == 0.f || rng_state, "vqh_embed_fwd: dropout needs rng_state");
+    DropCfg d{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks_for((long long)rows * H)), dim3(256), 0, stream, x, ldx, col0, W, b,
+                       pe, out, rows, L, H, d);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+// dW[H,3] and db[H] (beta*old + sum).  workspace >= 4*H*row_blocks floats
+extern "C" int vqh_embed_bwd(const float* dy, const float* x, int ldx, int col0, float* dW, float* db, float beta,
+                             int rows, int H, const unsigned long long* rng_state, unsigned drop_site, float drop_p,
+                             float* workspace, long long workspace_floats, hipStream_t stream) {
+    VQH_CHECK_ARG(rows >= 0 && H > 0, "vqh_embed_bwd: bad shape");
+    VQH_CHECK_ARG(dy && x && dW && db && workspace, "vqh_embed_bwd: null pointer");
+    VQH_CHECK_ARG(drop_p == 0.f || rng_state, "vqh_embed_bwd: dropout needs rng_state");
+    int rb = (rows + 255) / 256;
+    if (rb < 1) rb = 1;
+    if (rb > 128) rb = 128;
+    const int rpb = (rows + rb - 1) / rb > 0 ? (rows + rb - 1) / rb : 1;
+    VQH_CHECK_ARG((long long)rb * 4 * H <= workspace_floats, "vqh_embed_bwd: workspace too small");
+    DropCfg d{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((H + 63) / 64, rb), dim3(256), 0, stream, dy, x, ldx, col0, workspace, rows,
+                       H, rpb, d);
+    // slabs [blk][4][H]: gather weight column c into dW[h*3+c] needs a transposing reduce; reduce into a
+    // scratch [4][H] at the end of the workspace region first, then scatter.
+    VQH_LAUNCH_CHECK();
+    float* scratch = workspace + (size_t)rb * 4 * H;
+    VQH_CHECK_ARG((long long)rb * 4 * H + 4 * H <= workspace_floats, "vqh_embed_bwd: workspace too small");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(4 * H)), dim3(256), 0, stream, workspace, rb,
+                       (long long)4 * H, (long long)4 * H, scratch, 0.f);
+    // dW[h][c] = beta*dW + scratch[c][h] ; db[h] = beta*db + scratch[3][h]
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, scratch, dW, db, beta, H);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_bcast_rows(const float* p0, const float* p1, float* out, int B, long long n, hipStream_t stream) {
+    VQH_CHECK_ARG(B >= 0 && n >= 0, "vqh_bcast_rows: bad shape");
+    if (B == 0 || n == 0) return VQH_OK;
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(blocks_for((long long)B * n)), dim3(256), 0, stream, p0, p1, out, B, n);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_dropout_bwd(const float* dy, float* out, long long n, const unsigned long long* rng_state,
+                               unsigned drop_site, float drop_p, hipStream_t stream) {
+    VQH_CHECK_ARG(n >= 0 && drop_p > 0.f && drop_p < 1.f && rng_state, "vqh_dropout_bwd: bad argument");
+    if (n == 0) return VQH_OK;
+    DropCfg d{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, stream, dy, out, n, d);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_add(const float* a, const float* b, float* out, long long n, hipStream_t stream) {
+    VQH_CHECK_ARG(n >= 0, "vqh_add: bad n");
+    if (n == 0) return VQH_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, a, b, out, n);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_copy2d(const float* src, int lds_, float* dst, int ldd, int rows, int cols, hipStream_t stream) {
+    VQH_CHECK_ARG(rows >= 0 && cols >= 0 && lds_ >= cols && ldd >= cols, "vqh_copy2d: bad shape");
+    if (rows == 0 || cols == 0) return VQH_OK;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks_for((long long)rows * cols)), dim3(256), 0, stream, src, lds_, dst, ldd,
+                       rows, cols);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_sigmoid_bwd(const float* dy, const float* y, float* out, long long n, hipStream_t stream) {
+    VQH_CHECK_ARG(n >= 0, "vqh_sigmoid_bwd: bad n");
+    if (n == 0) return VQH_OK;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, dy, y, out, n);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_memset(void* ptr, int value, long long bytes, hipStream_t stream) {
+    VQH_CHECK_ARG(bytes >= 0, "vqh_memset: bad size");
+    if (bytes == 0) return VQH_OK;
+    hipError_t e = hipMemsetAsync(ptr, value, (size_t)bytes, stream);
+    if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+    return VQH_OK;
+}

@@ -1,0 +1,333 @@
+// EMA vector quantizer kernels (reference: VectorQuantizerEMA, /root/reference/models/vq_vae.py:19-283).
+//
+//   vqh_vq_nearest     argmin_k ||z_r - e_k||^2  (:183-188 / :238-244), first-minimum tie rule.
+//                      fp32 MFMA scores e.e - 2 z.e with top-2 tracking per row; rows whose top-2 gap is
+//                      inside the fp32 noise band (or exactly tied) are re-evaluated exactly in fp64 with
+//                      the direct sum (z-e)^2 form, lowest index winning ties.  The R x K distance matrix
+//                      is never materialised (the reference writes it twice: distances + one-hot).
+//   vqh_vq_gather      z_q = E[idx]; z_st = z + (z_q - z) (:189,:199); residual for the next RVQ level (:258)
+//   vqh_vq_segment_sum cnt[k] = #rows with idx==k, sum[k,:] = sum of those rows (:81-83, without the
+//                      dense one-hot GEMM); deterministic: one block per code, fixed reduction order.
+//   vqh_vq_ema_apply   ema <- d*ema + (1-d)*stat; E <- ema_emb / (ema_cnt + eps) for the WHOLE table (:85-89)
+//   vqh_vq_usage_stats perplexity / dead ratio / epoch accumulators (:201-220, :265-278)
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int kmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ void row_sqnorm_kernel(const float* __restrict__ X, int ld, int rows, int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float v = X[(size_t)row * ld + i];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+// one wave per 32 rows; codes in tiles of 32; D multiple of 8.
+__global__ __launch_bounds__(64, 2) void vq_nearest_kernel(const float* __restrict__ Z, int ldz,
+                                                           const float* __restrict__ E, int lde,
+                                                           const float* __restrict__ enorm,
+                                                           const float* __restrict__ znorm,
+                                                           long long* __restrict__ idx_out, int idx_offset,
+                                                           unsigned char* __restrict__ ambiguous, int R, int K, int D,
+                                                           float rel_tol) {
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * 32;
+    const int row = r0 + l31;
+    const bool rok = row < R;
+    const float* zp = Z + (size_t)row * ldz;
+    float best = INFINITY, second = INFINITY;
+    int bidx = 0x7fffffff;
+    const int ng = D / 8;
+    for (int c0 = 0; c0 < K; c0 += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int code_l = c0 + l31;
+        const float* ep = E + (size_t)code_l * lde;
+        for (int t = 0; t < ng; ++t) {
+            f32x4 ef = {0.f, 0.f, 0.f, 0.f}, zf = {0.f, 0.f, 0.f, 0.f};
+            if (code_l < K) ef = *reinterpret_cast<const f32x4*>(ep + 8 * t + 4 * h);
+            if (rok) zf = *reinterpret_cast<const f32x4*>(zp + 8 * t + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[j], zf[j], acc, 0, 0, 0);
+        }
+        // acc[r] = dot(E[c0 + kmap(r,h)], Z[row])
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int code = c0 + kmap(r, h);
+            if (code < K) {
+                const float d = enorm[code] - 2.f * acc[r];
+                if (d < best) {
+                    second = best;
+                    best = d;
+                    bidx = code;
+                } else if (d < second) {
+                    second = d;
+                }
+            }
+        }
+    }
+    // combine the two lane halves (same row, disjoint code subsets)
+    const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
+    const int oi = __shfl_xor(bidx, 32, 64);
+    float fb, fs;
+    int fi;
+    if (ob < best || (ob == best && oi < bidx)) {
+        fb = ob; fi = oi; fs = fminf(best, os);
+    } else {
+        fb = best; fi = bidx; fs = fminf(ob, second);
+    }
+    if (rok && h == 0) {
+        idx_out[row] = (long long)fi + idx_offset;
+        const float scale = znorm[row] + fabsf(fb) + 1e-30f;
+        ambiguous[row] = ((fs - fb) <= rel_tol * scale) ? 1 : 0;
+    }
+}
+
+// exact re-evaluation of flagged rows: fp64 direct form, lowest index wins ties. One wave per row.
+__global__ __launch_bounds__(256) void vq_refine_kernel(const float* __restrict__ Z, int ldz,
+                                                        const float* __restrict__ E, int lde,
+                                                        long long* __restrict__ idx_out, int idx_offset,
+                                                        const unsigned char* __restrict__ ambiguous, int R, int K,
+                                                        int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R || !ambiguous[row]) return;
+    const float* zp = Z + (size_t)row * ldz;
+    double best = 1e300;
+    int bidx = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+        const float* ep = E + (size_t)k * lde;
+        double s = 0.0;
+        for (int i = 0; i < D; ++i) {
+            const double d = (double)zp[i] - (double)ep[i];
+            s += d * d;
+        }
+        if (s < best) { best = s; bidx = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) idx_out[row] = (long long)bidx + idx_offset;
+}
+
+// z_q = E[idx - idx_offset]; z_st = z + (z_q - z); zq_acc (+)= z_q ; res_out = res_in - z_q
+__global__ void vq_gather_kernel(const float* __restrict__ E, int lde, const long long* __restrict__ idx,
+                                 int idx_offset, const float* __restrict__ rows_in, int ldr,
+                                 float* __restrict__ zq_level, float* __restrict__ res_out, int R, int D) {
+    const long long total = (long long)R * D;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / D), c = (int)(e % D);
+        const float q = E[(size_t)(idx[r] - idx_offset) * lde + c];
+        if (zq_level) zq_level[e] = q;
+        if (res_out) res_out[e] = __fsub_rn(rows_in[(size_t)r * ldr + c], q);
+    }
+}
+
+// z_q_total = sum over levels (in level order), z_st = z_e + (z_q_total - z_e)
+__global__ void vq_finish_kernel(const float* __restrict__ zq_levels, int Q, const float* __restrict__ ze, int ldz,
+                                 float* __restrict__ zq, float* __restrict__ zst, int R, int D) {
+    const long long total = (long long)R * D;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / D), c = (int)(e % D);
+        float s = zq_levels[e];
+        for (int l = 1; l < Q; ++l) s = __fadd_rn(s, zq_levels[(size_t)l * total + e]);
+        zq[e] = s;
+        const float z = ze[(size_t)r * ldz + c];
+        zst[e] = __fadd_rn(z, __fsub_rn(s, z));
+    }
+}
+
+// block per code k in [k0, k0+Kn): cnt[k], sum[k,:] over rows with idx[r] == k   (deterministic)
+template <int VPT>
+__global__ __launch_bounds__(256) void vq_segment_sum_kernel(const float* __restrict__ rows, int ldr,
+                                                             const long long* __restrict__ idx, int R, int D, int k0,
+                                                             float* __restrict__ cnt, float* __restrict__ sum) {
+    __shared__ float red[4][64 * VPT];
+    __shared__ int cred[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = k0 + blockIdx.x;
+    float acc[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) acc[j] = 0.f;
+    int c = 0;
+    const int per = (R + 3) / 4;
+    const int rbeg = wave * per, rend = min(R, rbeg + per);
+    for (int base = rbeg; base < rend; base += 64) {
+        const int r = base + lane;
+        const bool match = (r < rend) && (idx[r] == (long long)k);
+        unsigned long long mask = __ballot(match);
+        c += __popcll(mask);
+        while (mask) {
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float* rp = rows + (size_t)(base + bit) * ldr;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const int col = lane + 64 * j;
+                if (col < D) acc[j] += rp[col];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) red[wave][lane + 64 * j] = acc[j];
+    if (lane == 0) cred[wave] = c;
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256)
+        sum[(size_t)k * D + col] = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+    if (threadIdx.x == 0) cnt[k] = (float)(cred[0] + cred[1] + cred[2] + cred[3]);
+}
+
+// whole-table EMA refresh, arithmetic order of the reference (mul_, add_ of a scaled stat, divide)
+__global__ void vq_ema_apply_kernel(const float* __restrict__ cnt, const float* __restrict__ sum,
+                                    float* __restrict__ ema_cnt, float* __restrict__ ema_emb, float* __restrict__ emb,
+                                    int K, int D, float decay, float one_minus_decay, float eps) {
+    const long long total = (long long)K * D;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(e / D);
+        const float c_new = __fadd_rn(__fmul_rn(ema_cnt[k], decay), __fmul_rn(cnt[k], one_minus_decay));
+        const float e_new = __fadd_rn(__fmul_rn(ema_emb[e], decay), __fmul_rn(sum[e], one_minus_decay));
+        ema_emb[e] = e_new;
+        emb[e] = __fdiv_rn(e_new, __fadd_rn(c_new, eps));
+    }
+}
+__global__ void vq_ema_cnt_kernel(const float* __restrict__ cnt, float* __restrict__ ema_cnt, int K, float decay,
+                                  float one_minus_decay) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) ema_cnt[k] = __fadd_rn(__fmul_rn(ema_cnt[k], decay), __fmul_rn(cnt[k], one_minus_decay));
+}
+
+// usage[K] (float counts) -> stats[0] = perplexity, stats[1] = dead ratio; ep_usage += usage; ep_cnt += n
+__global__ __launch_bounds__(256) void vq_usage_stats_kernel(const float* __restrict__ usage, int K, float n_positions,
+                                                             float* __restrict__ ep_usage, float* __restrict__ ep_cnt,
+                                                             float* __restrict__ stats) {
+    __shared__ float red[3][4];
+    float tot = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) tot += usage[k];
+    tot = wave_sum(tot);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = tot;
+    __syncthreads();
+    tot = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float den = fmaxf(tot, 1.f);
+    float ent = 0.f, dead = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float u = usage[k];
+        const float p = u / den;
+        if (p > 0.f) ent += p * logf(p);
+        if (u == 0.f) dead += 1.f;
+        if (ep_usage) ep_usage[k] += u;
+    }
+    ent = wave_sum(ent);
+    dead = wave_sum(dead);
+    if ((threadIdx.x & 63) == 0) { red[1][threadIdx.x >> 6] = ent; red[2][threadIdx.x >> 6] = dead; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ent = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        dead = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        stats[0] = (tot > 0.f) ? expf(-ent) : 0.f;
+        stats[1] = dead / (float)K;
+        if (ep_cnt) ep_cnt[0] += n_positions;
+    }
+}
+
+inline int blocks_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
+}  // namespace
+
+// workspace: K (code norms) + R (row norms) floats, + R bytes (ambiguity flags) -> (K + R + R/4 + 1) floats
+extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset,
+                              int R, int K, int D, float rel_tol, float* workspace, long long workspace_floats,
+                              hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0 && K > 0 && D > 0 && (D % 8) == 0, "vqh_vq_nearest: D must be a positive multiple of 8");
+    if (R == 0) return VQH_OK;
+    VQH_CHECK_ARG(Z && E && idx_out && workspace, "vqh_vq_nearest: null pointer");
+    VQH_CHECK_ARG(((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(E)) & 15) == 0 && (ldz & 3) == 0 && (lde & 3) == 0,
+                  "vqh_vq_nearest: operands must be 16-byte aligned");
+    VQH_CHECK_ARG((long long)K + R + (R + 3) / 4 + 1 <= workspace_floats, "vqh_vq_nearest: workspace too small");
+    float* enorm = workspace;
+    float* znorm = workspace + K;
+    unsigned char* amb = reinterpret_cast<unsigned char*>(workspace + K + R);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, enorm);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, R, D, znorm);
+    hipLaunchKernelGGL(vq_nearest_kernel, dim3((R + 31) / 32), dim3(64), 0, stream, Z, ldz, E, lde, enorm, znorm, idx_out,
+                       idx_offset, amb, R, K, D, rel_tol);
+    hipLaunchKernelGGL(vq_refine_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, E, lde, idx_out, idx_offset, amb,
+                       R, K, D);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_vq_gather(const float* E, int lde, const long long* idx, int idx_offset, const float* rows_in,
+                             int ldr, float* zq_level, float* res_out, int R, int D, hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0 && D > 0, "vqh_vq_gather: bad shape");
+    if (R == 0) return VQH_OK;
+    VQH_CHECK_ARG(E && idx && (zq_level || res_out) && (!res_out || rows_in), "vqh_vq_gather: null pointer");
+    hipLaunchKernelGGL(vq_gather_kernel, dim3(blocks_for((long long)R * D)), dim3(256), 0, stream, E, lde, idx, idx_offset,
+                       rows_in, ldr, zq_level, res_out, R, D);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_vq_finish(const float* zq_levels, int Q, const float* ze, int ldz, float* zq, float* zst, int R, int D,
+                             hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0 && D > 0 && Q >= 1, "vqh_vq_finish: bad shape");
+    if (R == 0) return VQH_OK;
+    VQH_CHECK_ARG(zq_levels && ze && zq && zst, "vqh_vq_finish: null pointer");
+    hipLaunchKernelGGL(vq_finish_kernel, dim3(blocks_for((long long)R * D)), dim3(256), 0, stream, zq_levels, Q, ze, ldz, zq,
+                       zst, R, D);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+// cnt[k0..k0+Kn), sum[k0..k0+Kn, :] are overwritten.
+extern "C" int vqh_vq_segment_sum(const float* rows, int ldr, const long long* idx, int R, int D, int k0, int Kn,
+                                  float* cnt, float* sum, hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0 && D > 0 && D <= 1024 && Kn >= 0 && k0 >= 0, "vqh_vq_segment_sum: bad shape (D <= 1024)");
+    if (Kn == 0) return VQH_OK;
+    VQH_CHECK_ARG(rows && idx && cnt && sum, "vqh_vq_segment_sum: null pointer");
+#define SEG(V) hipLaunchKernelGGL((vq_segment_sum_kernel<V>), dim3(Kn), dim3(256), 0, stream, rows, ldr, idx, R, D, k0, cnt, sum)
+    if (D <= 64) SEG(1);
+    else if (D <= 128) SEG(2);
+    else if (D <= 256) SEG(4);
+    else if (D <= 512) SEG(8);
+    else SEG(16);
+#undef SEG
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_vq_ema_apply(const float* cnt, const float* sum, float* ema_cnt, float* ema_emb, float* emb, int K,
+                                int D, float decay, float one_minus_decay, float eps, hipStream_t stream) {
+    VQH_CHECK_ARG(K > 0 && D > 0, "vqh_vq_ema_apply: bad shape");
+    VQH_CHECK_ARG(cnt && sum && ema_cnt && ema_emb && emb, "vqh_vq_ema_apply: null pointer");
+    // embeddings first (they read the OLD ema_cnt and recompute the new one), then the counts
+    hipLaunchKernelGGL(vq_ema_apply_kernel, dim3(blocks_for((long long)K * D)), dim3(256), 0, stream, cnt, sum, ema_cnt,
+                       ema_emb, emb, K, D, decay, one_minus_decay, eps);
+    hipLaunchKernelGGL(vq_ema_cnt_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, cnt, ema_cnt, K, decay,
+                       one_minus_decay);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_vq_usage_stats(const float* usage, int K, float n_positions, float* ep_usage, float* ep_cnt,
+                                  float* stats, hipStream_t stream) {
+    VQH_CHECK_ARG(K > 0 && usage && stats, "vqh_vq_usage_stats: bad argument");
+    hipLaunchKernelGGL(vq_usage_stats_kernel, dim3(1), dim3(256), 0, stream, usage, K, n_positions, ep_usage, ep_cnt, stats);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}

@@ -1,0 +1,620 @@
+# -*- coding: utf-8 -*-
+"""
+StepEngine: the hand-scheduled forward / backward / optimizer step of the VQ-VAE hot path, written
+against the C ABI of libvqvae_hip.so (include/vqvae_hip.h).  No torch.autograd, no torch compute
+kernels: torch only provides device buffers, the current stream and (for N>1 ranks) RCCL through
+torch.distributed.  Every launch goes to the current stream, so a whole step can be captured into
+a hipGraph (torch.cuda.graph) and replayed.
+
+Mirrors, op for op, the reference call stack:
+  VQVAE.forward /root/reference/models/vq_vae.py:767-901  -> encode :639-660, LatentTokenizer :310-322,
+  to_code :736-743, VectorQuantizerEMA.forward :170-283, decode :745-765, loss_function :1097-1388,
+  then backward + clip_grad_norm_ + AdamW (/root/reference/experiment.py:169-197, run.py:191-197).
+
+Memory layout in HBM (all fp32, row-major):
+  * parameters / gradients / Adam moments: ONE flat buffer each (every tensor padded to 16 B), the
+    nn.Parameter objects are views -> grad all-reduce, global-norm clip and AdamW are single launches
+  * activations: [rows, features] matrices with rows = B*L (sequence side) or B*N (latent side);
+    attention reads heads in place from the packed QKV projection (no head transposes)
+  * residual-stream gradient: one [rows, H] buffer per stack, updated in place layer by layer
+"""
+import math
+
+import torch
+
+from . import lib as L
+from .lib import call
+
+FF = 2048            # torch default dim_feedforward of nn.Transformer{Encoder,Decoder}Layer
+SS_LAYERS = 2        # models/vq_vae.py:473
+LN_EPS = 1e-5
+VQ_EPS = 1e-5
+WS_FLOATS = 48 * 1024 * 1024
+
+METRIC_KEYS = ["loss", "Reconstruction_Loss_XYZ", "XYZ_MSE_Raw", "XYZ_MSE_Aligned", "Reconstruction_Loss_SS",
+               "SS_Accuracy", "VQ_Loss", "Geom_BondLength_Loss", "Geom_BondAngle_Loss", "Geom_Direction_Loss",
+               "Geom_Dihedral_Loss", "Geom_Loss", "SS_TV", "Usage_Reg", "XYZ_TV2", "VQ_Perplexity", "VQ_DeadRatio",
+               "RMSD_Raw", "RMSD_Aligned", "Geom_LocalPDM", "Geom_WinKabsch", "Frenet_Kappa", "Frenet_Tau",
+               "Geom_LongRangePDM"]
+OPTIONAL_METRICS = {"Geom_LocalPDM": "pdm_weight", "Geom_WinKabsch": "win_kabsch_weight", "Frenet_Kappa": "kappa_weight",
+                    "Frenet_Tau": "tau_weight", "Geom_LongRangePDM": "lr_pdm_weight"}
+
+
+class StepEngine:
+    def __init__(self, model, seed=0):
+        L.require_gpu()
+        self.m = model
+        self.dev = next(model.parameters()).device
+        if self.dev.type != "cuda":
+            raise L.VqhError("StepEngine: move the model to the GPU first (no CPU path exists)")
+        self.H = model.hidden_dim
+        self.D = model.code_dim
+        self.nh = model.num_heads
+        self.tnh = model.tokenizer_heads
+        self.N = model.latent_n_tokens
+        self.buf = {}
+        self.ws = torch.empty(WS_FLOATS, device=self.dev, dtype=torch.float32)
+        self.rng = torch.tensor([int(seed), 0], device=self.dev, dtype=torch.int64)
+        self.drop_scale = 1.0                      # 0.0 disables every dropout site (parity runs)
+        self._sites = {}
+        self._flatten()
+        self.hyper = torch.zeros(8, device=self.dev, dtype=torch.float32)
+        self.norm = torch.zeros(2, device=self.dev, dtype=torch.float32)
+        self.norm_ws = torch.empty(1024, device=self.dev, dtype=torch.float64)
+        self.metrics = torch.zeros(len(METRIC_KEYS), device=self.dev, dtype=torch.float32)
+        self.vq_stats = torch.zeros(2, device=self.dev, dtype=torch.float32)
+        self.opt_step = 0
+        self.train = True
+        self.ctx = None
+
+    # ------------------------------------------------------------------ parameters
+    def _flatten(self):
+        """Re-home every parameter into one flat buffer (views), plus flat grad / Adam moments."""
+        named = list(self.m.named_parameters())
+        offs, total = {}, 0
+        for n, p in named:
+            offs[n] = total
+            total += (p.numel() + 3) // 4 * 4
+        self.flat_p = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.P, self.G = {}, {}
+        with torch.no_grad():
+            for n, p in named:
+                o, k = offs[n], p.numel()
+                view = self.flat_p[o:o + k].view(p.shape)
+                view.copy_(p.detach().to(self.dev, torch.float32))
+                p.data = view
+                self.P[n] = view
+                self.G[n] = self.flat_g[o:o + k].view(p.shape)
+        self.n_flat = total
+        self.offsets = offs
+
+    def params_in_sync(self):
+        for n, p in self.m.named_parameters():
+            if p.data_ptr() != self.P[n].data_ptr():
+                return False
+        return True
+
+    def attach_grads(self):
+        """Expose the flat gradient as .grad views (drop-in optimizers / inspection)."""
+        for n, p in self.m.named_parameters():
+            p.grad = self.G[n]
+
+    # ------------------------------------------------------------------ buffers / helpers
+    def T(self, name, *shape, dtype=torch.float32):
+        t = self.buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(*shape, device=self.dev, dtype=dtype)
+            self.buf[name] = t
+        return t
+
+    def site(self, name):
+        s = self._sites.get(name)
+        if s is None:
+            s = len(self._sites) + 1
+            self._sites[name] = s
+        return s
+
+    def pdrop(self, p):
+        return float(p) * self.drop_scale if self.train else 0.0
+
+    # ---- primitive wrappers -------------------------------------------------------------------
+    def ln_fwd(self, name, x, ldx, y, ldy, rows, tag):
+        mean, rstd = self.T(tag + ".mean", rows), self.T(tag + ".rstd", rows)
+        call("vqh_layernorm_fwd", x, ldx, self.P[name + ".weight"], self.P[name + ".bias"], y, ldy, mean, rstd, rows,
+             self.H, LN_EPS)
+        return mean, rstd
+
+    def ln_bwd(self, name, dy, lddy, x, ldx, tag, dx, lddx, accumulate, rows):
+        call("vqh_layernorm_bwd", dy, lddy, x, ldx, self.P[name + ".weight"], self.buf[tag + ".mean"],
+             self.buf[tag + ".rstd"], dx, lddx, int(accumulate), self.G[name + ".weight"], self.G[name + ".bias"], 0.0,
+             rows, self.H, self.ws, self.ws.numel())
+
+    def lin_fwd(self, x, ldx, rows, W, b, out, ldo, mode=L.EPI_LINEAR, aux_in=None, aux_out=None, ldaux=0, site=0, p=0.0):
+        N, K = W.shape
+        L.gemm(1, 1, rows, N, K, x, ldx, W, K, out, ldo, bias=b, mode=mode, aux_in=aux_in, aux_out=aux_out, ldaux=ldaux,
+               rng=self.rng, site=site, p=p)
+
+    def lin_dgrad(self, dy, lddy, rows, W, dx, lddx, mode=L.EPI_LINEAR, aux_in=None, ldaux=0, beta=0.0, p=0.0):
+        N, K = W.shape          # dx[rows,K] = dy[rows,N] . W[N,K]
+        L.gemm(1, 0, rows, K, N, dy, lddy, W, K, dx, lddx, mode=mode, aux_in=aux_in, ldaux=ldaux, beta=beta, p=p)
+
+    def lin_wgrad(self, dy, lddy, x, ldx, rows, gW, gb):
+        N, K = gW.shape         # gW[N,K] = dy[rows,N]^T . x[rows,K]
+        L.gemm(0, 0, N, K, rows, dy, lddy, x, ldx, gW, K, ws=self.ws)
+        if gb is not None:
+            call("vqh_colsum", dy, lddy, rows, N, gb, 0.0, self.ws, self.ws.numel())
+
+    def drop_bwd(self, dy, n, site, p, tag):
+        """dy * keep-mask of a DROP_RESID site (identity when p == 0)."""
+        if p <= 0.0:
+            return dy
+        out = self.T(tag, n)
+        call("vqh_dropout_bwd", dy, out, n, self.rng, site, p)
+        return out
+
+    # ------------------------------------------------------------------ attention module
+    def mha_fwd(self, pre, q_in, kv_in, rows_q, rows_kv, B, T, S, nh, kvalid, p_attn, self_attn):
+        H = self.H
+        W, bias = self.P[pre + ".in_proj_weight"], self.P[pre + ".in_proj_bias"]
+        if self_attn:
+            qkv = self.T(pre + ".qkv", rows_q, 3 * H)
+            self.lin_fwd(q_in, H, rows_q, W, bias, qkv, 3 * H)
+            q, k, v, ldq, ldk = qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H
+        else:
+            qp = self.T(pre + ".q", rows_q, H)
+            kvp = self.T(pre + ".kv", rows_kv, 2 * H)
+            self.lin_fwd(q_in, H, rows_q, W[:H], bias[:H], qp, H)
+            self.lin_fwd(kv_in, H, rows_kv, W[H:], bias[H:], kvp, 2 * H)
+            q, k, v, ldq, ldk = qp, kvp, kvp[:, H:], H, 2 * H
+        ao = self.T(pre + ".ao", rows_q, H)
+        lse = self.T(pre + ".lse", B * nh * T)
+        call("vqh_attn_fwd", q, ldq, k, ldk, v, ldk, ao, H, lse, kvalid, B, nh, T, S, H // nh, self.rng,
+             self.site(pre + ".attn_drop"), p_attn)
+        return ao
+
+    def mha_bwd(self, pre, d_ao, q_in, kv_in, rows_q, rows_kv, B, T, S, nh, kvalid, p_attn, self_attn,
+                d_q_in, d_kv_in, kv_beta):
+        """d_ao: grad of the head-concatenated attention output (before out_proj).
+        Writes d_q_in (beta 0) and, for cross attention, d_kv_in (beta kv_beta)."""
+        H = self.H
+        W = self.P[pre + ".in_proj_weight"]
+        gW, gb = self.G[pre + ".in_proj_weight"], self.G[pre + ".in_proj_bias"]
+        ao, lse = self.buf[pre + ".ao"], self.buf[pre + ".lse"]
+        dsum = self.T("tmp.dsum", B * nh * T)
+        site = self.site(pre + ".attn_drop")
+        if self_attn:
+            qkv = self.buf[pre + ".qkv"]
+            dqkv = self.T("tmp.dqkv", rows_q, 3 * H)
+            call("vqh_attn_bwd", qkv, 3 * H, qkv[:, H:], 3 * H, qkv[:, 2 * H:], 3 * H, ao, H, lse, d_ao, H, dsum,
+                 dqkv, 3 * H, dqkv[:, H:], 3 * H, dqkv[:, 2 * H:], 3 * H, kvalid, B, nh, T, S, H // nh, self.rng, site, p_attn)
+            self.lin_wgrad(dqkv, 3 * H, q_in, H, rows_q, gW, gb)
+            self.lin_dgrad(dqkv, 3 * H, rows_q, W, d_q_in, H)
+        else:
+            qp, kvp = self.buf[pre + ".q"], self.buf[pre + ".kv"]
+            dq = self.T("tmp.dq", rows_q, H)
+            dkv = self.T("tmp.dkv", rows_kv, 2 * H)
+            call("vqh_attn_bwd", qp, H, kvp, 2 * H, kvp[:, H:], 2 * H, ao, H, lse, d_ao, H, dsum,
+                 dq, H, dkv, 2 * H, dkv[:, H:], 2 * H, kvalid, B, nh, T, S, H // nh, self.rng, site, p_attn)
+            self.lin_wgrad(dq, H, q_in, H, rows_q, gW[:H], gb[:H])
+            self.lin_wgrad(dkv, 2 * H, kv_in, H, rows_kv, gW[H:], gb[H:])
+            self.lin_dgrad(dq, H, rows_q, W[:H], d_q_in, H)
+            self.lin_dgrad(dkv, 2 * H, rows_kv, W[H:], d_kv_in, H, beta=kv_beta)
+
+    # ------------------------------------------------------------------ transformer blocks
+    def attn_block_fwd(self, pre, attn, norm, x0, rows, B, T, nh, kvalid, mem=None, rows_kv=None, S=None, p=0.1):
+        """x1 = x0 + dropout(out_proj(MHA(LN(x0) [, mem])))"""
+        H = self.H
+        h = self.T(f"{pre}.{norm}.y", rows, H)
+        self.ln_fwd(f"{pre}.{norm}", x0, H, h, H, rows, f"{pre}.{norm}")
+        self_attn = mem is None
+        ao = self.mha_fwd(f"{pre}.{attn}", h, h if self_attn else mem, rows, rows if self_attn else rows_kv, B, T,
+                          T if self_attn else S, nh, kvalid, self.pdrop(p), self_attn)
+        x1 = self.T(f"{pre}.{attn}.out", rows, H)
+        self.lin_fwd(ao, H, rows, self.P[f"{pre}.{attn}.out_proj.weight"], self.P[f"{pre}.{attn}.out_proj.bias"], x1, H,
+                     mode=L.EPI_DROP_RESID, aux_in=x0, ldaux=H, site=self.site(f"{pre}.{attn}.drop"), p=self.pdrop(p))
+        return x1
+
+    def attn_block_bwd(self, pre, attn, norm, x0, dres, rows, B, T, nh, kvalid, mem=None, rows_kv=None, S=None,
+                       d_mem=None, mem_beta=0.0, p=0.1):
+        """dres holds d x1 on entry and d x0 on exit (in place)."""
+        H = self.H
+        a = f"{pre}.{attn}"
+        self_attn = mem is None
+        h = self.buf[f"{pre}.{norm}.y"]
+        dy = self.drop_bwd(dres, rows * H, self.site(a + ".drop"), self.pdrop(p), "tmp.dy")
+        self.lin_wgrad(dy, H, self.buf[a + ".ao"], H, rows, self.G[a + ".out_proj.weight"], self.G[a + ".out_proj.bias"])
+        d_ao = self.T("tmp.dao", rows, H)
+        self.lin_dgrad(dy, H, rows, self.P[a + ".out_proj.weight"], d_ao, H)
+        dh = self.T("tmp.dh", rows, H)
+        self.mha_bwd(a, d_ao, h, h if self_attn else mem, rows, rows if self_attn else rows_kv, B, T,
+                     T if self_attn else S, nh, kvalid, self.pdrop(p), self_attn, dh, d_mem, mem_beta)
+        self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dres, H, True, rows)
+
+    def ffn_block_fwd(self, pre, norm, lin1, lin2, x0, rows, act, p_inner, p_out):
+        """x1 = x0 + dropout(lin2(dropout(act(lin1(LN(x0))))))   act: 'relu' (encoder/decoder) or 'gelu' (tokenizer)"""
+        H = self.H
+        h = self.T(f"{pre}.{norm}.y", rows, H)
+        self.ln_fwd(f"{pre}.{norm}", x0, H, h, H, rows, f"{pre}.{norm}")
+        W1, b1 = self.P[f"{pre}.{lin1}.weight"], self.P[f"{pre}.{lin1}.bias"]
+        F = W1.shape[0]
+        f1 = self.T(f"{pre}.{lin1}.y", rows, F)
+        if act == "relu":
+            self.lin_fwd(h, H, rows, W1, b1, f1, F, mode=L.EPI_RELU_DROP, site=self.site(f"{pre}.{lin1}.drop"),
+                         p=self.pdrop(p_inner))
+        else:
+            pre_act = self.T(f"{pre}.{lin1}.pre", rows, F)
+            self.lin_fwd(h, H, rows, W1, b1, f1, F, mode=L.EPI_GELU, aux_out=pre_act, ldaux=F)
+        x1 = self.T(f"{pre}.{lin2}.out", rows, H)
+        self.lin_fwd(f1, F, rows, self.P[f"{pre}.{lin2}.weight"], self.P[f"{pre}.{lin2}.bias"], x1, H,
+                     mode=L.EPI_DROP_RESID, aux_in=x0, ldaux=H, site=self.site(f"{pre}.{lin2}.drop"), p=self.pdrop(p_out))
+        return x1
+
+    def ffn_block_bwd(self, pre, norm, lin1, lin2, x0, dres, rows, act, p_inner, p_out):
+        H = self.H
+        W1, W2 = self.P[f"{pre}.{lin1}.weight"], self.P[f"{pre}.{lin2}.weight"]
+        F = W1.shape[0]
+        f1 = self.buf[f"{pre}.{lin1}.y"]
+        h = self.buf[f"{pre}.{norm}.y"]
+        dy = self.drop_bwd(dres, rows * H, self.site(f"{pre}.{lin2}.drop"), self.pdrop(p_out), "tmp.dy")
+        self.lin_wgrad(dy, H, f1, F, rows, self.G[f"{pre}.{lin2}.weight"], self.G[f"{pre}.{lin2}.bias"])
+        if act == "relu":
+            # d pre-activation, written over the saved post-activation (read-then-write per element)
+            self.lin_dgrad(dy, H, rows, W2, f1, F, mode=L.EPI_MUL_POSMASK, aux_in=f1, ldaux=F, p=self.pdrop(p_inner))
+            dpre = f1
+        else:
+            dpre = self.buf[f"{pre}.{lin1}.pre"]
+            self.lin_dgrad(dy, H, rows, W2, dpre, F, mode=L.EPI_MUL_GELUGRAD, aux_in=dpre, ldaux=F)
+        self.lin_wgrad(dpre, F, h, H, rows, self.G[f"{pre}.{lin1}.weight"], self.G[f"{pre}.{lin1}.bias"])
+        dh = self.T("tmp.dh", rows, H)
+        self.lin_dgrad(dpre, F, rows, W1, dh, H)
+        self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dres, H, True, rows)
+
+    # ------------------------------------------------------------------ model sections
+    def encode(self, x, mask):
+        """models/vq_vae.py:639-660 -> h_fuse [B*L, H] (also keeps h_enc_geo / h_enc_ss buffers)."""
+        B, Lq, _ = x.shape
+        H, ML = self.H, B * Lq
+        c = self.ctx
+        c["x"], c["mask"], c["B"], c["L"] = x, mask, B, Lq
+        pe = self.m.pos_enc[0]
+        g = self.T("geo.x0", ML, H)
+        call("vqh_embed_fwd", x, 6, 0, self.P["input_proj.weight"], self.P["input_proj.bias"], pe, g, ML, Lq, H,
+             self.rng, self.site("inp_dropout"), self.pdrop(0.1))
+        xs = [g]
+        for i in range(self.m.num_layers):
+            pre = f"encoder.layers.{i}"
+            g = self.attn_block_fwd(pre, "self_attn", "norm1", g, ML, B, Lq, self.nh, mask)
+            xs.append(g)
+            g = self.ffn_block_fwd(pre, "norm2", "linear1", "linear2", g, ML, "relu", 0.1, 0.1)
+            xs.append(g)
+        c["geo_xs"] = xs
+        h_geo = self.T("enc_ln.y", ML, H)
+        self.ln_fwd("enc_ln", g, H, h_geo, H, ML, "enc_ln")
+        cat = self.T("fuse.cat", ML, 2 * H)
+        self.ln_fwd("ln_geo", h_geo, H, cat, 2 * H, ML, "ln_geo")
+        s = self.T("ss.x0", ML, H)
+        call("vqh_embed_fwd", x, 6, 3, self.P["ss_input_proj.weight"], self.P["ss_input_proj.bias"], pe, s, ML, Lq, H,
+             self.rng, 0, 0.0)
+        xs = [s]
+        for i in range(SS_LAYERS):
+            pre = f"ss_encoder.layers.{i}"
+            s = self.attn_block_fwd(pre, "self_attn", "norm1", s, ML, B, Lq, self.nh, mask)
+            xs.append(s)
+            s = self.ffn_block_fwd(pre, "norm2", "linear1", "linear2", s, ML, "relu", 0.1, 0.1)
+            xs.append(s)
+        c["ss_xs"] = xs
+        self.ln_fwd("ln_ss", s, H, cat[:, H:], 2 * H, ML, "ln_ss")
+        f0, f0pre = self.T("fuse.f0", ML, H), self.T("fuse.f0pre", ML, H)
+        self.lin_fwd(cat, 2 * H, ML, self.P["fuse_mlp.0.weight"], self.P["fuse_mlp.0.bias"], f0, H, mode=L.EPI_GELU,
+                     aux_out=f0pre, ldaux=H)
+        f2 = self.T("fuse.f2", ML, H)
+        self.lin_fwd(f0, H, ML, self.P["fuse_mlp.2.weight"], self.P["fuse_mlp.2.bias"], f2, H)
+        hf = self.T("fuse.out", ML, H)
+        self.ln_fwd("fuse_mlp.3", f2, H, hf, H, ML, "fuse_mlp.3")
+        return hf, h_geo, s
+
+    def encode_bwd(self, d_hf):
+        c = self.ctx
+        B, Lq, H = c["B"], c["L"], self.H
+        ML, mask = B * Lq, c["mask"]
+        df2 = self.T("tmp.df2", ML, H)
+        self.ln_bwd("fuse_mlp.3", d_hf, H, self.buf["fuse.f2"], H, "fuse_mlp.3", df2, H, False, ML)
+        self.lin_wgrad(df2, H, self.buf["fuse.f0"], H, ML, self.G["fuse_mlp.2.weight"], self.G["fuse_mlp.2.bias"])
+        f0pre = self.buf["fuse.f0pre"]
+        self.lin_dgrad(df2, H, ML, self.P["fuse_mlp.2.weight"], f0pre, H, mode=L.EPI_MUL_GELUGRAD, aux_in=f0pre, ldaux=H)
+        cat = self.buf["fuse.cat"]
+        self.lin_wgrad(f0pre, H, cat, 2 * H, ML, self.G["fuse_mlp.0.weight"], self.G["fuse_mlp.0.bias"])
+        dcat = self.T("tmp.dcat", ML, 2 * H)
+        self.lin_dgrad(f0pre, H, ML, self.P["fuse_mlp.0.weight"], dcat, 2 * H)
+        # ---- secondary-structure branch
+        xs = c["ss_xs"]
+        dres = self.T("tmp.dres_seq", ML, H)
+        self.ln_bwd("ln_ss", dcat[:, H:], 2 * H, xs[-1], H, "ln_ss", dres, H, False, ML)
+        for i in reversed(range(SS_LAYERS)):
+            pre = f"ss_encoder.layers.{i}"
+            self.ffn_block_bwd(pre, "norm2", "linear1", "linear2", xs[2 * i + 1], dres, ML, "relu", 0.1, 0.1)
+            self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask)
+        call("vqh_embed_bwd", dres, c["x"], 6, 3, self.G["ss_input_proj.weight"], self.G["ss_input_proj.bias"], 0.0, ML, H,
+             self.rng, 0, 0.0, self.ws, self.ws.numel())
+        # ---- geometry branch
+        xs = c["geo_xs"]
+        dhg = self.T("tmp.dh", ML, H)
+        self.ln_bwd("ln_geo", dcat, 2 * H, self.buf["enc_ln.y"], H, "ln_geo", dhg, H, False, ML)
+        self.ln_bwd("enc_ln", dhg, H, xs[-1], H, "enc_ln", dres, H, False, ML)
+        for i in reversed(range(self.m.num_layers)):
+            pre = f"encoder.layers.{i}"
+            self.ffn_block_bwd(pre, "norm2", "linear1", "linear2", xs[2 * i + 1], dres, ML, "relu", 0.1, 0.1)
+            self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask)
+        call("vqh_embed_bwd", dres, c["x"], 6, 0, self.G["input_proj.weight"], self.G["input_proj.bias"], 0.0, ML, H,
+             self.rng, self.site("inp_dropout"), self.pdrop(0.1), self.ws, self.ws.numel())
+
+    def tokenize(self, hf, mask, B, Lq):
+        """LatentTokenizer + to_code (models/vq_vae.py:310-322, 736-743) -> z_e [B*N, D]"""
+        H, N, D = self.H, self.N, self.D
+        MN, ML = B * N, B * Lq
+        c = self.ctx
+        pd = self.m.tokenizer_dropout
+        q = self.T("tok.q0", MN, H)
+        call("vqh_bcast_rows", self.P["tokenizer.queries"], None, q, B, N * H)
+        qs = [q]
+        for i in range(self.m.tokenizer_layers):
+            pre = f"tokenizer.layers.{i}"
+            qn, kvn = self.T(pre + ".ln_q.y", MN, H), self.T(pre + ".ln_kv.y", ML, H)
+            self.ln_fwd(pre + ".ln_q", q, H, qn, H, MN, pre + ".ln_q")
+            self.ln_fwd(pre + ".ln_kv", hf, H, kvn, H, ML, pre + ".ln_kv")
+            ao = self.mha_fwd(pre + ".attn", qn, kvn, MN, ML, B, N, Lq, self.tnh, mask, self.pdrop(pd), False)
+            q1 = self.T(pre + ".attn.out", MN, H)
+            self.lin_fwd(ao, H, MN, self.P[pre + ".attn.out_proj.weight"], self.P[pre + ".attn.out_proj.bias"], q1, H,
+                         mode=L.EPI_DROP_RESID, aux_in=q, ldaux=H, site=self.site(pre + ".drop"), p=self.pdrop(pd))
+            qs.append(q1)
+            q = self.ffn_block_fwd(pre, "ln_o", "ffn.0", "ffn.2", q1, MN, "gelu", 0.0, pd)
+            qs.append(q)
+        c["tok_qs"] = qs
+        z_e = self.T("tok.z_e", MN, D)
+        sig = self.m.latent_sigmoid and ((not self.m.latent_sigmoid_ae_only) or (not self.m.use_vq))
+        c["sigmoid"] = sig
+        self.lin_fwd(q, H, MN, self.P["to_code.weight"], self.P["to_code.bias"], z_e, D,
+                     mode=L.EPI_SIGMOID if sig else L.EPI_LINEAR)
+        return z_e
+
+    def tokenize_bwd(self, d_ze):
+        """d_ze [B*N, D] (consumed) -> d_hf [B*L, H]"""
+        c = self.ctx
+        B, Lq, H, N, D = c["B"], c["L"], self.H, self.N, self.D
+        MN, ML, mask = B * N, B * Lq, c["mask"]
+        pd = self.m.tokenizer_dropout
+        qs = c["tok_qs"]
+        if c["sigmoid"]:
+            call("vqh_sigmoid_bwd", d_ze, self.buf["tok.z_e"], d_ze, MN * D)
+        self.lin_wgrad(d_ze, D, qs[-1], H, MN, self.G["to_code.weight"], self.G["to_code.bias"])
+        dres = self.T("tmp.dres_tok", MN, H)
+        self.lin_dgrad(d_ze, D, MN, self.P["to_code.weight"], dres, H)
+        d_hf = self.T("tmp.d_hf", ML, H)
+        nl = self.m.tokenizer_layers
+        for i in reversed(range(nl)):
+            pre = f"tokenizer.layers.{i}"
+            a = pre + ".attn"
+            self.ffn_block_bwd(pre, "ln_o", "ffn.0", "ffn.2", qs[2 * i + 1], dres, MN, "gelu", 0.0, pd)
+            dy = self.drop_bwd(dres, MN * H, self.site(pre + ".drop"), self.pdrop(pd), "tmp.dy_tok")
+            self.lin_wgrad(dy, H, self.buf[a + ".ao"], H, MN, self.G[a + ".out_proj.weight"], self.G[a + ".out_proj.bias"])
+            d_ao = self.T("tmp.dao_tok", MN, H)
+            self.lin_dgrad(dy, H, MN, self.P[a + ".out_proj.weight"], d_ao, H)
+            dqn, dkvn = self.T("tmp.dqn", MN, H), self.T("tmp.dkvn", ML, H)
+            self.mha_bwd(a, d_ao, self.buf[pre + ".ln_q.y"], self.buf[pre + ".ln_kv.y"], MN, ML, B, N, Lq, self.tnh, mask,
+                         self.pdrop(pd), False, dqn, dkvn, 0.0)
+            self.ln_bwd(pre + ".ln_q", dqn, H, qs[2 * i], H, pre + ".ln_q", dres, H, True, MN)
+            self.ln_bwd(pre + ".ln_kv", dkvn, H, self.buf["fuse.out"], H, pre + ".ln_kv", d_hf, H, i != nl - 1, ML)
+        call("vqh_colsum", dres, N * H, B, N * H, self.G["tokenizer.queries"], 0.0, self.ws, self.ws.numel())
+        return d_hf
+
+    def quantize(self, z_e, B, do_ema_update):
+        """VectorQuantizerEMA.forward (models/vq_vae.py:170-283). z_e [B*N, D] -> z_st, z_q, idx, stats"""
+        q = self.m.quantizer
+        D, R = self.D, z_e.shape[0]
+        Q, Kp, K = q.num_quantizers, q.K_per, q.K
+        emb = q.embedding
+        idx = self.T("vq.idx", Q * R, dtype=torch.int64)
+        zq_lv = self.T("vq.zq_levels", Q, R, D)
+        cnt, ssum = self.T("vq.cnt", K), self.T("vq.sum", K, D)
+        usage = self.T("vq.usage", K)
+        upd = bool(self.train and do_ema_update)
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size() > 1
+        rows = z_e
+        res = [self.T("vq.res0", R, D), self.T("vq.res1", R, D)]
+        for lv in range(Q):
+            lo = lv * Kp
+            tab = emb[lo:lo + Kp]
+            ids = idx[lv * R:(lv + 1) * R]
+            call("vqh_vq_nearest", rows, D, tab, D, ids, lo, R, Kp, D, 3e-5, self.ws, self.ws.numel())
+            nxt = res[lv & 1] if lv + 1 < Q else None
+            # gather uses the table BEFORE this level's EMA refresh (:189 precedes :191-197 / :248 precedes :251-258)
+            call("vqh_vq_gather", tab, D, ids, lo, rows, D, zq_lv[lv], nxt, R, D)
+            # per-code statistics of THIS level (other code ranges stay zero: the reference refreshes the whole table)
+            call("vqh_memset", cnt, 0, K * 4)
+            call("vqh_memset", ssum, 0, K * D * 4)
+            call("vqh_vq_segment_sum", rows, D, ids, R, D, lo, Kp, cnt, ssum)
+            call("vqh_copy2d", cnt[lo:], Kp, usage[lo:], Kp, 1, Kp)
+            if upd:
+                if multi:                                   # RCCL sum of the EMA statistics over ranks
+                    torch.distributed.all_reduce(cnt)
+                    torch.distributed.all_reduce(ssum)
+                d = float(q.decay)
+                call("vqh_vq_ema_apply", cnt, ssum, q.ema_cluster_size, q.ema_embedding, emb, K, D,
+                     _f32(d), _f32(1.0 - d), VQ_EPS)
+            rows = nxt
+        z_q, z_st = self.T("vq.z_q", R, D), self.T("vq.z_st", R, D)
+        call("vqh_vq_finish", zq_lv, Q, z_e, D, z_q, z_st, R, D)
+        call("vqh_vq_usage_stats", usage, K, float(Q * R), q._ep_usage, q._ep_cnt, self.vq_stats)
+        return z_st, z_q, idx, self.vq_stats
+
+    def decode(self, z, mask, B, Lq):
+        """models/vq_vae.py:745-765. z [B*N, D] -> recons [B*L, 6]"""
+        H, N, D = self.H, self.N, self.D
+        MN, ML = z.shape[0], B * Lq
+        Nmem = MN // B
+        c = self.ctx
+        c["dec_B"], c["dec_L"], c["dec_N"], c["dec_z"], c["dec_mask"] = B, Lq, Nmem, z, mask
+        memf = self.T("dec.memf", MN, H)
+        self.lin_fwd(z, D, MN, self.P["from_code.weight"], self.P["from_code.bias"], memf, H)
+        mem = self.T("dec.mem", MN, H)
+        self.ln_fwd("mem_ln", memf, H, mem, H, MN, "mem_ln")
+        t = self.T("dec.x0", ML, H)
+        call("vqh_bcast_rows", self.P["query_embed.weight"], self.m.pos_enc[0], t, B, Lq * H)
+        xs = [t]
+        for i in range(self.m.num_layers):
+            pre = f"decoder.layers.{i}"
+            t = self.attn_block_fwd(pre, "self_attn", "norm1", t, ML, B, Lq, self.nh, mask)
+            xs.append(t)
+            t = self.attn_block_fwd(pre, "multihead_attn", "norm2", t, ML, B, Lq, self.nh, None, mem=mem, rows_kv=MN, S=Nmem)
+            xs.append(t)
+            t = self.ffn_block_fwd(pre, "norm3", "linear1", "linear2", t, ML, "relu", 0.1, 0.1)
+            xs.append(t)
+        c["dec_xs"] = xs
+        rec = self.T("dec.recons", ML, 6)
+        self.lin_fwd(t, H, ML, self.P["head_xyz.weight"], self.P["head_xyz.bias"], rec, 6)
+        self.lin_fwd(t, H, ML, self.P["head_ss.weight"], self.P["head_ss.bias"], rec[:, 3:], 6)
+        return rec
+
+    def decode_bwd(self, d_rec, d_z, z_beta):
+        """d_rec [B*L, 6] -> d_z [B*N, D] written as z_beta*d_z + grad (straight-through adds onto the commitment grad)."""
+        c = self.ctx
+        B, Lq, Nmem, H, D = c["dec_B"], c["dec_L"], c["dec_N"], self.H, self.D
+        ML, MN, mask = B * Lq, B * c["dec_N"], c["dec_mask"]
+        xs = c["dec_xs"]
+        t = xs[-1]
+        self.lin_wgrad(d_rec, 6, t, H, ML, self.G["head_xyz.weight"], self.G["head_xyz.bias"])
+        self.lin_wgrad(d_rec[:, 3:], 6, t, H, ML, self.G["head_ss.weight"], self.G["head_ss.bias"])
+        dres = self.T("tmp.dres_seq", ML, H)
+        self.lin_dgrad(d_rec, 6, ML, self.P["head_xyz.weight"], dres, H)
+        self.lin_dgrad(d_rec[:, 3:], 6, ML, self.P["head_ss.weight"], dres, H, beta=1.0)
+        mem = self.buf["dec.mem"]
+        d_mem = self.T("tmp.d_mem", MN, H)
+        nl = self.m.num_layers
+        for i in reversed(range(nl)):
+            pre = f"decoder.layers.{i}"
+            self.ffn_block_bwd(pre, "norm3", "linear1", "linear2", xs[3 * i + 2], dres, ML, "relu", 0.1, 0.1)
+            self.attn_block_bwd(pre, "multihead_attn", "norm2", xs[3 * i + 1], dres, ML, B, Lq, self.nh, None, mem=mem,
+                                rows_kv=MN, S=Nmem, d_mem=d_mem, mem_beta=0.0 if i == nl - 1 else 1.0)
+            self.attn_block_bwd(pre, "self_attn", "norm1", xs[3 * i], dres, ML, B, Lq, self.nh, mask)
+        # tgt = query_embed[:L] + pos_enc[:L] broadcast over the batch
+        gq = self.G["query_embed.weight"]
+        call("vqh_memset", gq, 0, gq.numel() * 4)
+        call("vqh_colsum", dres, Lq * H, B, Lq * H, gq, 0.0, self.ws, self.ws.numel())
+        dmemf = self.T("tmp.dmemf", MN, H)
+        self.ln_bwd("mem_ln", d_mem, H, self.buf["dec.memf"], H, "mem_ln", dmemf, H, False, MN)
+        self.lin_wgrad(dmemf, H, c["dec_z"], D, MN, self.G["from_code.weight"], self.G["from_code.bias"])
+        self.lin_dgrad(dmemf, H, MN, self.P["from_code.weight"], d_z, D, beta=z_beta)
+
+    # ------------------------------------------------------------------ whole step
+    def forward(self, x, mask, train=True):
+        """VQVAE.forward (models/vq_vae.py:767-901) without aug/noise/soft-VQ (see DESIGN.md scope)."""
+        m = self.m
+        self.train = bool(train)
+        self.ctx = {}
+        B, Lq, _ = x.shape
+        if m.use_vq:
+            ws = m.ema_decay_warm_steps
+            if m._ema_decay_override is not None:
+                m.quantizer.decay = float(m._ema_decay_override)
+            elif ws <= 0:
+                m.quantizer.decay = float(m.ema_decay_end)
+            else:
+                t = min(1.0, max(0.0, m.training_steps) / float(ws))
+                m.quantizer.decay = float((1.0 - t) * m.ema_decay_start + t * m.ema_decay_end)
+        hf, _, _ = self.encode(x, mask)
+        if self.train:
+            m.training_steps += 1
+        z_e = self.tokenize(hf, mask, B, Lq)
+        c = self.ctx
+        if not m.use_vq:
+            z_dec, z_q, idx, stats = z_e, z_e, None, None
+        else:
+            upd = self.train and (m.training_steps >= m.ema_update_freeze_steps)
+            z_dec, z_q, idx, stats = self.quantize(z_e, B, upd)
+        rec = self.decode(z_dec, mask, B, Lq)
+        c["z_e"], c["z_q"], c["idx"], c["rec"], c["stats"] = z_e, z_q, idx, rec, stats
+        return rec, z_e, z_q, idx, stats
+
+    def loss(self, rec, target, mask, z_e, z_q, stats, weights):
+        """VQVAE.loss_function (models/vq_vae.py:1097-1388): metrics (device vector) + d_rec, d_ze."""
+        m = self.m
+        B, Lq = target.shape[0], target.shape[1]
+        if m.usage_entropy_lambda > 0.0:
+            raise NotImplementedError("usage_entropy_lambda > 0 is not on the HIP path yet (0 in both shipped configs)")
+        if m._data_std is not None:
+            raise NotImplementedError("set_data_stats() rescaling is not on the HIP path (never called by the harness)")
+        g = lambda k, d: float(weights.get(k, d))
+        w = [g("rmsd_weight", 1.0), g("ss_weight", 1.0), g("bond_length_weight", 0.0), g("bond_angle_weight", 0.0),
+             g("dir_weight", 0.0), g("dih_weight", 0.0), g("xyz_tv_lambda", 0.0), g("pdm_weight", 0.0),
+             g("win_kabsch_weight", 0.0), g("kappa_weight", 0.0), g("tau_weight", 0.0), g("lr_pdm_weight", 0.0),
+             float(m.xyz_align_alpha), float(m.ss_tv_lambda), float(m.label_smoothing or 0.0),
+             float(m.quantizer.beta) if m.use_vq else 0.0]
+        ip = [int(weights.get("pdm_window", 8)), int(weights.get("win_kabsch_size", 16)),
+              int(weights.get("win_kabsch_stride", 8)), int(weights.get("lr_min_sep", 24)),
+              int(weights.get("lr_stride", 8)), int(weights.get("lr_max_offsets", 8))]
+        import ctypes as C
+        wa = (C.c_float * 16)(*w)
+        ia = (C.c_int * 6)(*ip)
+        d_rec = self.T("loss.d_rec", B * Lq, 6)
+        use_vq = bool(m.use_vq)
+        Ntok = z_e.shape[0] // B
+        d_ze = self.T("loss.d_ze", z_e.shape[0], self.D)
+        call("vqh_loss_fwd_bwd", rec, target, mask, 1 if mask is not None else 0, z_e if use_vq else None,
+             z_q if use_vq else None, stats if use_vq else None, B, Lq, Ntok, self.D, int(use_vq),
+             C.cast(wa, C.c_void_p).value, C.cast(ia, C.c_void_p).value, d_rec, d_ze if use_vq else None, self.metrics,
+             self.ws, self.ws.numel())
+        if self.ctx is None:
+            self.ctx = {}
+        self.ctx["d_rec"], self.ctx["d_ze"], self.ctx["weights"] = d_rec, d_ze, dict(weights)
+        return self.metrics
+
+    def backward(self):
+        """Fill the flat gradient buffer from the d_rec / d_ze left by loss()."""
+        c = self.ctx
+        d_ze = c["d_ze"]
+        self.decode_bwd(c["d_rec"], d_ze, 1.0 if self.m.use_vq else 0.0)
+        d_hf = self.tokenize_bwd(d_ze)
+        self.encode_bwd(d_hf)
+
+    def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8):
+        """Host -> device scalars of the next optimizer step (async copy on the current stream)."""
+        self.opt_step += 1
+        t = self.opt_step
+        h = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, max_norm if max_norm else 0.0,
+                          1.0 - betas[0] ** t, 1.0 - betas[1] ** t], dtype=torch.float32)
+        self.hyper.copy_(h, non_blocking=False)
+
+    def optimizer_step(self):
+        """clip_grad_norm_(max_norm) + AdamW over the flat buffers (hyper-parameters from self.hyper)."""
+        call("vqh_grad_norm", self.flat_g, self.n_flat, self.hyper, self.norm, self.norm_ws)
+        call("vqh_adamw_step", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n_flat, self.hyper, self.norm)
+
+    def allreduce_grads(self):
+        """DDP semantics: average the flat gradient over ranks with ONE RCCL all-reduce."""
+        d = torch.distributed
+        if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
+            d.all_reduce(self.flat_g, op=d.ReduceOp.AVG if self.flat_g.is_cuda else d.ReduceOp.SUM)
+
+    def advance_rng(self):
+        call("vqh_rng_advance", self.rng)
+
+    def metrics_dict(self, weights=None):
+        vals = self.metrics.tolist()
+        weights = weights if weights is not None else (self.ctx or {}).get("weights", {})
+        out = {}
+        for k, v in zip(METRIC_KEYS, vals):
+            wk = OPTIONAL_METRICS.get(k)
+            if wk is not None and not float(weights.get(wk, 0.0)) > 0:
+                continue
+            out[k] = v
+        return out
+
+
+def _f32(x):
+    """Round a python double to the fp32 value torch uses when a tensor is multiplied by a scalar."""
+    import struct
+    return struct.unpack("f", struct.pack("f", float(x)))[0]

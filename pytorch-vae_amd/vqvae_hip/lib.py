@@ -1,0 +1,100 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libvqvae_hip.so (the C ABI declared in include/vqvae_hip.h).
+
+There is NO fallback: if the shared library is missing, or no GPU is present when a kernel is
+called, callers get a loud VqhError.  PyTorch is used only for device memory (tensors), the current
+HIP stream and torch.distributed; every arithmetic kernel of the training step lives in the library."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqvae_hip.so")
+_lib = None
+
+
+class VqhError(RuntimeError):
+    pass
+
+
+# i=int  f=float  p=pointer  l=long long  u=unsigned
+_PROTOS = {
+    "vqh_rng_advance": "pp",
+    "vqh_memset": "pilp",
+    "vqh_gemm": "iiiiipipipipippifpufplp",
+    "vqh_layernorm_fwd": "pipppippiifp",
+    "vqh_layernorm_bwd": "pipippppiippfiiplp",
+    "vqh_reduce_slabs": "pillpfp",
+    "vqh_colsum": "piiipfplp",
+    "vqh_embed_fwd": "piippppiiipufp",
+    "vqh_embed_bwd": "ppiippfiipufplp",
+    "vqh_bcast_rows": "pppilp",
+    "vqh_dropout_bwd": "pplpufp",
+    "vqh_add": "ppplp",
+    "vqh_copy2d": "pipiiip",
+    "vqh_sigmoid_bwd": "ppplp",
+    "vqh_attn_fwd": "pipipipippiiiiipufp",
+    "vqh_attn_bwd": "pipipipippippipipipiiiiipufp",
+    "vqh_vq_nearest": "pipipiiiifplp",
+    "vqh_vq_gather": "pipipippiip",
+    "vqh_vq_finish": "pipippiip",
+    "vqh_vq_segment_sum": "pipiiiippp",
+    "vqh_vq_ema_apply": "pppppiifffp",
+    "vqh_vq_usage_stats": "pifpppp",
+    "vqh_loss_fwd_bwd": "pppipppiiiiipppppplp",
+    "vqh_grad_norm": "plpppp",
+    "vqh_adamw_step": "pppplppp",
+}
+_CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "l": C.c_longlong, "u": C.c_uint}
+EXPORTS = ["vqh_last_error", "vqh_abi_version"] + list(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise VqhError(f"HIP extension not built: {LIB_PATH} is missing "
+                           f"(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                           f"There is no CPU fallback for the product path.")
+        L = C.CDLL(LIB_PATH)
+        L.vqh_last_error.restype = C.c_char_p
+        L.vqh_abi_version.restype = C.c_int
+        for name, sig in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.argtypes = [_CT[c] for c in sig]
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise VqhError("vqvae_hip needs an MI355X (gfx950) GPU: the product path has no CPU fallback")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an entry point on the current torch stream (appended as the last argument)."""
+    conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+    rc = getattr(lib(), name)(*conv, _stream())
+    if rc != 0:
+        raise VqhError(f"{name} failed (rc={rc}): {lib().vqh_last_error().decode()}")
+
+
+# epilogue modes of vqh_gemm
+EPI_LINEAR, EPI_RELU_DROP, EPI_GELU, EPI_DROP_RESID, EPI_SIGMOID, EPI_MUL_POSMASK, EPI_MUL_GELUGRAD, EPI_MUL_SIGGRAD = range(8)
+
+
+def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, mode=EPI_LINEAR, aux_in=None, aux_out=None,
+         ldaux=0, beta=0.0, rng=None, site=0, p=0.0, ws=None):
+    call("vqh_gemm", int(a_kc), int(b_kc), M, N, K, _p(A), lda, _p(B), ldb, _p(Cout), ldc, _p(bias), mode,
+         _p(aux_in), _p(aux_out), ldaux, float(beta), _p(rng), site, float(p), _p(ws),
+         (ws.numel() if ws is not None else 0))
