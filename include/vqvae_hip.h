@@ -120,7 +120,8 @@ int vqh_loss_fwd_bwd(const float* recons, const float* target, const unsigned ch
                      float* workspace, long long workspace_floats, vqh_stream_t stream);
 
 /* clip_grad_norm_ + torch.optim.AdamW over flat buffers (experiment.py:170, run.py:191-197).
- * hyper (device floats): lr, beta1, beta2, eps, weight_decay, max_norm, 1-beta1^t, 1-beta2^t
+ * hyper (device, 9 floats): lr, beta1, beta2, eps, weight_decay, max_norm, 1-beta1^t, 1-beta2^t,
+ *                            grad_scale (1/world_size when the gradient buffer holds a SUM over ranks)
  * norm_out (device, 2 floats): total grad norm, clip coefficient */
 int vqh_grad_norm(const float* g, long long n, const float* hyper, float* norm_out, double* workspace,
                   vqh_stream_t stream);

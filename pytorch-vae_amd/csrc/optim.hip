@@ -35,17 +35,19 @@ __global__ void gradnorm_finish_kernel(const double* __restrict__ part, int npar
     for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
     s = wave_sum_d(s);
     if (threadIdx.x == 0) {
-        const float nrm = (float)sqrt(s);
+        // hyper[8] = gradient scale (1/world_size after a SUM all-reduce; 1 otherwise)
+        const float gscale = hyper[8];
+        const float nrm = (float)sqrt(s) * gscale;
         norm_out[0] = nrm;
         const float max_norm = hyper[5];
-        float coef = 1.f;
-        if (max_norm > 0.f) coef = fminf(1.f, max_norm / (nrm + 1e-6f));
+        float coef = gscale;
+        if (max_norm > 0.f) coef = gscale * fminf(1.f, max_norm / (nrm + 1e-6f));
         norm_out[1] = coef;
     }
 }
 
 // hyper (device, floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=max_norm
-//                         [6]=bias_correction1 = 1-beta1^t  [7]=bias_correction2 = 1-beta2^t
+//                         [6]=bias_correction1 = 1-beta1^t  [7]=bias_correction2 = 1-beta2^t  [8]=grad scale
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n,
                                                     const float* __restrict__ hyper, const float* __restrict__ norm) {

@@ -173,6 +173,7 @@ class VectorQuantizerEMA(nn.Module):
         B, M, D = z_e.shape
         eng = self._owner()._engine()
         eng.train = self.training
+        eng.defer_ema = False
         with torch.no_grad():
             z_st, z_q, idx, stats = eng.quantize(z_e.reshape(B * M, D).contiguous(), B, do_ema_update)
         idx_out = idx.view(B, M).clone() if self.num_quantizers == 1 else idx.clone()
@@ -427,6 +428,57 @@ class VQVAE(nn.Module):
         if getattr(self, "_anchor_t", None) is None or self._anchor_t.device != self.head_xyz.weight.device:
             self._anchor_t = torch.zeros((), device=self.head_xyz.weight.device, requires_grad=True)
         return self._anchor_t
+
+    # ---- fused step interface used by the harness (experiment.py) -----------------------------------
+    def train_step(self, x, mask, weights, lr, weight_decay, clip, betas=(0.9, 0.999), use_graph=True):
+        """forward + loss + backward + (RCCL all-reduce) + clip + AdamW + EMA refresh; returns the device metric
+        vector (order = vqvae_hip.engine.METRIC_KEYS).  Steady state is a hipGraph replay."""
+        eng = self._engine()
+        x, mask = self._prep(x, mask)
+        dev = self.head_xyz.weight.device
+        eng.betas = tuple(betas)
+        return eng.train_step(x.to(dev, non_blocking=True), mask.to(dev, non_blocking=True) if mask is not None else None,
+                              weights, lr, weight_decay, clip, use_graph=use_graph)
+
+    @torch.no_grad()
+    def eval_step(self, x, mask, weights):
+        eng = self._engine()
+        x, mask = self._prep(x, mask)
+        dev = self.head_xyz.weight.device
+        return eng.eval_step(x.to(dev), mask.to(dev) if mask is not None else None, weights)
+
+    def metric_names(self):
+        return list(METRIC_KEYS)
+
+    def metric_sums(self):
+        """Device-side running sums of the metric vector over the train steps since reset_metric_sums()."""
+        return self._engine().metrics_acc
+
+    def reset_metric_sums(self):
+        eng = self._engine()
+        _L.call("vqh_memset", eng.metrics_acc, 0, eng.metrics_acc.numel() * 4)
+
+    def optimizer_state(self):
+        """AdamW state in torch.optim's state_dict layout (for Lightning-style checkpoints)."""
+        eng = self._engine()
+        state, names = {}, [n for n, _ in self.named_parameters()]
+        for i, n in enumerate(names):
+            o, k = eng.offsets[n], eng.P[n].numel()
+            state[i] = {"step": torch.tensor(float(eng.opt_step)), "exp_avg": eng.flat_m[o:o + k].view(eng.P[n].shape).clone(),
+                        "exp_avg_sq": eng.flat_v[o:o + k].view(eng.P[n].shape).clone()}
+        return {"state": state, "param_groups": [{"params": list(range(len(names)))}]}
+
+    def load_optimizer_state(self, sd):
+        eng = self._engine()
+        names = [n for n, _ in self.named_parameters()]
+        for i, n in enumerate(names):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            o, k = eng.offsets[n], eng.P[n].numel()
+            eng.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            eng.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            eng.opt_step = int(float(st["step"]))
 
     def backward(self):
         """Explicit HIP backward of the last forward + loss_function (fast path used by the trainer)."""

@@ -58,7 +58,11 @@ class StepEngine:
         self.drop_scale = 1.0                      # 0.0 disables every dropout site (parity runs)
         self._sites = {}
         self._flatten()
-        self.hyper = torch.zeros(8, device=self.dev, dtype=torch.float32)
+        self.hyper = torch.zeros(9, device=self.dev, dtype=torch.float32)
+        self.metrics_acc = torch.zeros(len(METRIC_KEYS), device=self.dev, dtype=torch.float32)
+        self.graphs = {}
+        self._seen = {}
+        self._pending_ema = None
         self.norm = torch.zeros(2, device=self.dev, dtype=torch.float32)
         self.norm_ws = torch.empty(1024, device=self.dev, dtype=torch.float64)
         self.metrics = torch.zeros(len(METRIC_KEYS), device=self.dev, dtype=torch.float32)
@@ -66,6 +70,7 @@ class StepEngine:
         self.opt_step = 0
         self.train = True
         self.ctx = None
+        self.defer_ema = False
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -75,8 +80,12 @@ class StepEngine:
         for n, p in named:
             offs[n] = total
             total += (p.numel() + 3) // 4 * 4
+        q = getattr(self.m, "quantizer", None)
+        self.n_stats = (q.K + q.K * q.D + 3) // 4 * 4 if q is not None else 0
         self.flat_p = torch.zeros(total, device=self.dev, dtype=torch.float32)
-        self.flat_g = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        # gradients, followed by the per-step EMA statistics [cnt(K) | sum(K*D)]: one RCCL all-reduce covers both
+        self.flat_gx = torch.zeros(total + self.n_stats, device=self.dev, dtype=torch.float32)
+        self.flat_g = self.flat_gx[:total]
         self.flat_m = torch.zeros(total, device=self.dev, dtype=torch.float32)
         self.flat_v = torch.zeros(total, device=self.dev, dtype=torch.float32)
         self.P, self.G = {}, {}
@@ -418,8 +427,10 @@ class StepEngine:
         emb = q.embedding
         idx = self.T("vq.idx", Q * R, dtype=torch.int64)
         zq_lv = self.T("vq.zq_levels", Q, R, D)
-        cnt, ssum = self.T("vq.cnt", K), self.T("vq.sum", K, D)
+        cnt = self.flat_gx[self.n_flat:self.n_flat + K]
+        ssum = self.flat_gx[self.n_flat + K:self.n_flat + K + K * D].view(K, D)
         usage = self.T("vq.usage", K)
+        defer = bool(self.defer_ema and Q == 1)
         upd = bool(self.train and do_ema_update)
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size() > 1
@@ -438,18 +449,32 @@ class StepEngine:
             call("vqh_memset", ssum, 0, K * D * 4)
             call("vqh_vq_segment_sum", rows, D, ids, R, D, lo, Kp, cnt, ssum)
             call("vqh_copy2d", cnt[lo:], Kp, usage[lo:], Kp, 1, Kp)
-            if upd:
+            if upd and defer:
+                # single level: this step's z_q already used the old table (:189 precedes :191-197), so the refresh
+                # may run after backward, behind the combined gradient + statistics all-reduce
+                self._pending_ema = float(q.decay)
+            elif upd:
                 if multi:                                   # RCCL sum of the EMA statistics over ranks
-                    torch.distributed.all_reduce(cnt)
-                    torch.distributed.all_reduce(ssum)
-                d = float(q.decay)
-                call("vqh_vq_ema_apply", cnt, ssum, q.ema_cluster_size, q.ema_embedding, emb, K, D,
-                     _f32(d), _f32(1.0 - d), VQ_EPS)
+                    torch.distributed.all_reduce(self.flat_gx[self.n_flat:])
+                self.apply_ema(float(q.decay))
             rows = nxt
         z_q, z_st = self.T("vq.z_q", R, D), self.T("vq.z_st", R, D)
         call("vqh_vq_finish", zq_lv, Q, z_e, D, z_q, z_st, R, D)
         call("vqh_vq_usage_stats", usage, K, float(Q * R), q._ep_usage, q._ep_cnt, self.vq_stats)
         return z_st, z_q, idx, self.vq_stats
+
+    def apply_ema(self, decay):
+        q = self.m.quantizer
+        K, D = q.K, q.D
+        cnt = self.flat_gx[self.n_flat:self.n_flat + K]
+        ssum = self.flat_gx[self.n_flat + K:self.n_flat + K + K * D]
+        call("vqh_vq_ema_apply", cnt, ssum, q.ema_cluster_size, q.ema_embedding, q.embedding, K, D,
+             _f32(decay), _f32(1.0 - decay), VQ_EPS)
+
+    def finish_ema(self):
+        if self._pending_ema is not None:
+            self.apply_ema(self._pending_ema)
+            self._pending_ema = None
 
     def decode(self, z, mask, B, Lq):
         """models/vq_vae.py:745-765. z [B*N, D] -> recons [B*L, 6]"""
@@ -512,10 +537,15 @@ class StepEngine:
     # ------------------------------------------------------------------ whole step
     def forward(self, x, mask, train=True):
         """VQVAE.forward (models/vq_vae.py:767-901) without aug/noise/soft-VQ (see DESIGN.md scope)."""
-        m = self.m
         self.train = bool(train)
-        self.ctx = {}
-        B, Lq, _ = x.shape
+        upd = self._host_prologue()
+        out = self._forward_core(x, mask, upd)
+        self.finish_ema()
+        return out
+
+    def _host_prologue(self):
+        """Host-side state of one forward: EMA decay schedule (:795-802), step counter (:805-806), freeze (:825)."""
+        m = self.m
         if m.use_vq:
             ws = m.ema_decay_warm_steps
             if m._ema_decay_override is not None:
@@ -525,15 +555,20 @@ class StepEngine:
             else:
                 t = min(1.0, max(0.0, m.training_steps) / float(ws))
                 m.quantizer.decay = float((1.0 - t) * m.ema_decay_start + t * m.ema_decay_end)
-        hf, _, _ = self.encode(x, mask)
         if self.train:
             m.training_steps += 1
+        return bool(self.train and m.use_vq and (m.training_steps >= m.ema_update_freeze_steps))
+
+    def _forward_core(self, x, mask, upd):
+        m = self.m
+        self.ctx = {}
+        B, Lq, _ = x.shape
+        hf, _, _ = self.encode(x, mask)
         z_e = self.tokenize(hf, mask, B, Lq)
         c = self.ctx
         if not m.use_vq:
             z_dec, z_q, idx, stats = z_e, z_e, None, None
         else:
-            upd = self.train and (m.training_steps >= m.ema_update_freeze_steps)
             z_dec, z_q, idx, stats = self.quantize(z_e, B, upd)
         rec = self.decode(z_dec, mask, B, Lq)
         c["z_e"], c["z_q"], c["idx"], c["rec"], c["stats"] = z_e, z_q, idx, rec, stats
@@ -580,12 +615,12 @@ class StepEngine:
         d_hf = self.tokenize_bwd(d_ze)
         self.encode_bwd(d_hf)
 
-    def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8):
-        """Host -> device scalars of the next optimizer step (async copy on the current stream)."""
+    def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """Host -> device scalars of the next optimizer step (copied on the current stream, outside any graph)."""
         self.opt_step += 1
         t = self.opt_step
         h = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, max_norm if max_norm else 0.0,
-                          1.0 - betas[0] ** t, 1.0 - betas[1] ** t], dtype=torch.float32)
+                          1.0 - betas[0] ** t, 1.0 - betas[1] ** t, grad_scale], dtype=torch.float32)
         self.hyper.copy_(h, non_blocking=False)
 
     def optimizer_step(self):
@@ -593,11 +628,95 @@ class StepEngine:
         call("vqh_grad_norm", self.flat_g, self.n_flat, self.hyper, self.norm, self.norm_ws)
         call("vqh_adamw_step", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n_flat, self.hyper, self.norm)
 
-    def allreduce_grads(self):
-        """DDP semantics: average the flat gradient over ranks with ONE RCCL all-reduce."""
+    def world(self):
         d = torch.distributed
-        if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
-            d.all_reduce(self.flat_g, op=d.ReduceOp.AVG if self.flat_g.is_cuda else d.ReduceOp.SUM)
+        return d.get_world_size() if (d.is_available() and d.is_initialized()) else 1
+
+    def allreduce_grads(self):
+        """ONE RCCL all-reduce (sum) over [gradients | EMA statistics]; the 1/world gradient average is folded
+        into the clip coefficient (hyper[8]), the statistics are wanted as sums."""
+        if self.world() > 1:
+            torch.distributed.all_reduce(self.flat_gx if self._pending_ema is not None else self.flat_g)
+
+    # ------------------------------------------------------------------ fused training step
+    def _step_part_a(self, x, mask, weights, upd):
+        self.advance_rng()
+        rec, z_e, z_q, idx, stats = self._forward_core(x, mask, upd)
+        self.loss(rec, x, mask, z_e, z_q, stats, weights)
+        self.backward()
+
+    def _step_part_b(self):
+        self.finish_ema()
+        self.optimizer_step()
+        call("vqh_add", self.metrics_acc, self.metrics, self.metrics_acc, self.metrics.numel())
+
+    def train_step(self, x, mask, weights, lr, weight_decay, clip, use_graph=True):
+        """One whole training step (experiment.py:453 training_step + Lightning backward/clip/AdamW) on the GPU.
+        Steady state = hipGraph replays; results land in self.metrics (device).  The captured graph holds every
+        kernel of the step; for world_size > 1 it is split around the single RCCL all-reduce."""
+        m = self.m
+        self.train = True
+        self.defer_ema = True
+        upd = self._host_prologue()
+        world = self.world()
+        self.set_hyper(lr, weight_decay, clip, betas=getattr(self, "betas", (0.9, 0.999)), grad_scale=1.0 / world)
+        decay = float(m.quantizer.decay) if m.use_vq else 0.0
+        key = (tuple(x.shape), mask is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
+               world, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0))
+        xs = self.T("in.x", *x.shape)
+        xs.copy_(x, non_blocking=True)
+        ms = None
+        if mask is not None:
+            ms = self.T("in.mask", *mask.shape, dtype=torch.bool)
+            ms.copy_(mask, non_blocking=True)
+        g = self.graphs.get(key) if use_graph else None
+        if g is not None:
+            g[0].replay()
+            if world > 1:
+                self._pending_ema = decay if (upd and m.num_quantizers == 1) else None
+                self.allreduce_grads()
+                self._pending_ema = None
+            if g[1] is not None:
+                g[1].replay()
+            return self.metrics
+        seen = self._seen.get(key, 0)
+        self._seen[key] = seen + 1
+        can_capture = use_graph and seen >= 1 and not (world > 1 and m.use_vq and m.num_quantizers > 1)
+        if not can_capture:
+            self._step_part_a(xs, ms, weights, upd)
+            self.allreduce_grads()
+            self._step_part_b()
+            return self.metrics
+        torch.cuda.synchronize()
+        ga = torch.cuda.CUDAGraph()
+        gb = None
+        if world == 1:
+            with torch.cuda.graph(ga):
+                self._step_part_a(xs, ms, weights, upd)
+                self._step_part_b()
+        else:
+            with torch.cuda.graph(ga):
+                self._step_part_a(xs, ms, weights, upd)
+            pend = self._pending_ema
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                self._step_part_b()
+            self._pending_ema = pend
+        self.graphs[key] = (ga, gb)
+        ga.replay()
+        if world > 1:
+            self.allreduce_grads()
+            self._pending_ema = None
+            gb.replay()
+        return self.metrics
+
+    def eval_step(self, x, mask, weights):
+        self.train = False
+        self.defer_ema = False
+        upd = self._host_prologue()
+        rec, z_e, z_q, idx, stats = self._forward_core(x, mask, upd)
+        self.loss(rec, x, mask, z_e, z_q, stats, weights)
+        return self.metrics
 
     def advance_rng(self):
         call("vqh_rng_advance", self.rng)

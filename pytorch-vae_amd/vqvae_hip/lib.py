@@ -93,8 +93,22 @@ def call(name, *args):
 EPI_LINEAR, EPI_RELU_DROP, EPI_GELU, EPI_DROP_RESID, EPI_SIGMOID, EPI_MUL_POSMASK, EPI_MUL_GELUGRAD, EPI_MUL_SIGGRAD = range(8)
 
 
+PROFILE = None   # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+
+
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, mode=EPI_LINEAR, aux_in=None, aux_out=None,
          ldaux=0, beta=0.0, rng=None, site=0, p=0.0, ws=None):
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws)
+        e1.record()
+        PROFILE.append((f"{int(bool(a_kc))},{int(bool(b_kc))}", M, N, K, e0, e1))
+        return
+    _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws)
+
+
+def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws):
     call("vqh_gemm", int(a_kc), int(b_kc), M, N, K, _p(A), lda, _p(B), ldb, _p(Cout), ldc, _p(bias), mode,
          _p(aux_in), _p(aux_out), ldaux, float(beta), _p(rng), site, float(p), _p(ws),
          (ws.numel() if ws is not None else 0))

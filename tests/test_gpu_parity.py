@@ -342,7 +342,7 @@ def test_adamw_and_clip_match_torch():
     opt = torch.optim.AdamW([ref_p], lr=1e-3, weight_decay=0.01)
     P, Gd = p0.clone().to(DEV), torch.empty(n, device=DEV)
     Mm, V = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    hyper, norm = torch.zeros(8, device=DEV), torch.zeros(2, device=DEV)
+    hyper, norm = torch.zeros(9, device=DEV), torch.zeros(2, device=DEV)
     ws = torch.empty(1024, device=DEV, dtype=torch.float64)
     for t in range(1, 4):
         gt = g0 * t
@@ -350,7 +350,7 @@ def test_adamw_and_clip_match_torch():
         gn = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
         opt.step()
         Gd.copy_(gt)
-        hyper.copy_(torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 1 - 0.9 ** t, 1 - 0.999 ** t]))
+        hyper.copy_(torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 1 - 0.9 ** t, 1 - 0.999 ** t, 1.0]))
         L.call("vqh_grad_norm", Gd, n, hyper, norm, ws)
         L.call("vqh_adamw_step", P, Gd, Mm, V, n, hyper, norm)
         assert abs(float(norm[0]) - float(gn)) < 1e-5 * float(gn)
