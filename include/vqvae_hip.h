@@ -100,7 +100,7 @@ int vqh_vq_gather(const float* E, int lde, const long long* idx, int idx_offset,
 int vqh_vq_finish(const float* zq_levels, int Q, const float* ze, int ldz, float* zq, float* zst, int R, int D,
                   vqh_stream_t stream);
 int vqh_vq_segment_sum(const float* rows, int ldr, const long long* idx, int R, int D, int k0, int Kn, float* cnt,
-                       float* sum, vqh_stream_t stream);
+                       float* sum, float* workspace, long long workspace_floats, vqh_stream_t stream);
 int vqh_vq_ema_apply(const float* cnt, const float* sum, float* ema_cnt, float* ema_emb, float* emb, int K, int D,
                      float decay, float one_minus_decay, float eps, vqh_stream_t stream);
 int vqh_vq_usage_stats(const float* usage, int K, float n_positions, float* ep_usage, float* ep_cnt, float* stats,

@@ -112,12 +112,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // out[i] = beta*out[i] + sum_s slabs[s*stride + i]
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, long long stride, long long n,
-                                    float* __restrict__ out, float beta) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += slabs[(size_t)k * stride + i];
-        out[i] = (beta != 0.f) ? beta * out[i] + s : s;
+// block = 64 columns x 16 slab lanes: every thread sums S/16 slabs with independent loads, the 16 partials of
+// a column are combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, int S, long long stride,
+                                                            long long n, float* __restrict__ out, float beta) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (i < n) {
+        int k = ty;
+        for (; k + 48 < S; k += 64) {
+            const float a = slabs[(size_t)k * stride + i], b = slabs[(size_t)(k + 16) * stride + i];
+            const float c = slabs[(size_t)(k + 32) * stride + i], d = slabs[(size_t)(k + 48) * stride + i];
+            s += (a + b) + (c + d);
+        }
+        for (; k < S; k += 16) s += slabs[(size_t)k * stride + i];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][tx];
+        out[i] = (beta != 0.f) ? beta * out[i] + t : t;
     }
 }
 
@@ -280,7 +298,7 @@ extern "C" int vqh_reduce_slabs(const float* slabs, int S, long long stride, lon
                                 hipStream_t stream) {
     VQH_CHECK_ARG(S >= 0 && n >= 0, "vqh_reduce_slabs: bad shape");
     if (n == 0) return VQH_OK;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, slabs, S, stride, n, out, beta);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, stream, slabs, S, stride, n, out, beta);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
@@ -308,9 +326,9 @@ extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int 
 #undef LN_BWD
     VQH_LAUNCH_CHECK();
     // slab layout [blk][2][H]: dw = sum_blk slab[blk][0], db = sum_blk slab[blk][1]
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(H)), dim3(256), 0, stream, workspace, nblk, (long long)2 * H,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, workspace, nblk, (long long)2 * H,
                        (long long)H, dw, beta);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(H)), dim3(256), 0, stream, workspace + H, nblk,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, workspace + H, nblk,
                        (long long)2 * H, (long long)H, db, beta);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
@@ -328,7 +346,7 @@ extern "C" int vqh_colsum(const float* X, int ld, int M, int N, float* out, floa
     const int rows_per_block = (M + rb - 1) / rb > 0 ? (M + rb - 1) / rb : 1;
     VQH_CHECK_ARG((long long)rb * N <= workspace_floats, "vqh_colsum: workspace too small");
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, rb), dim3(256), 0, stream, X, ld, M, N, workspace, rows_per_block);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(N)), dim3(256), 0, stream, workspace, rb, (long long)N,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, workspace, rb, (long long)N,
                        (long long)N, out, beta);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
@@ -368,7 +386,7 @@ extern "C" int vqh_embed_bwd(const float* dy, const float* x, int ldx, int col0,
     VQH_LAUNCH_CHECK();
     float* scratch = workspace + (size_t)rb * 4 * H;
     VQH_CHECK_ARG((long long)rb * 4 * H + 4 * H <= workspace_floats, "vqh_embed_bwd: workspace too small");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(4 * H)), dim3(256), 0, stream, workspace, rb,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((4 * H + 63) / 64), dim3(1024), 0, stream, workspace, rb,
                        (long long)4 * H, (long long)4 * H, scratch, 0.f);
     // dW[h][c] = beta*dW + scratch[c][h] ; db[h] = beta*db + scratch[3][h]
     hipLaunchKernelGGL(embed_scatter_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, scratch, dW, db, beta, H);

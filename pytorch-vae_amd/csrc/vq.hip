@@ -168,15 +168,25 @@ __global__ __launch_bounds__(256) void vq_segment_sum_kernel(const float* __rest
         const bool match = (r < rend) && (idx[r] == (long long)k);
         unsigned long long mask = __ballot(match);
         c += __popcll(mask);
-        while (mask) {
-            const int bit = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const float* rp = rows + (size_t)(base + bit) * ldr;
+        while (mask) {      // up to 4 matching rows per trip so their loads are in flight together
+            int bits[4];
 #pragma unroll
-            for (int j = 0; j < VPT; ++j) {
-                const int col = lane + 64 * j;
-                if (col < D) acc[j] += rp[col];
+            for (int u = 0; u < 4; ++u) {
+                bits[u] = mask ? __ffsll((long long)mask) - 1 : -1;
+                if (mask) mask &= mask - 1;
             }
+            float v[4][VPT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    const int col = lane + 64 * j;
+                    v[u][j] = (bits[u] >= 0 && col < D) ? rows[(size_t)(base + bits[u]) * ldr + col] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) acc[j] += v[u][j];
         }
     }
 #pragma unroll
@@ -186,6 +196,66 @@ __global__ __launch_bounds__(256) void vq_segment_sum_kernel(const float* __rest
     for (int col = threadIdx.x; col < D; col += 256)
         sum[(size_t)k * D + col] = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
     if (threadIdx.x == 0) cnt[k] = (float)(cred[0] + cred[1] + cred[2] + cred[3]);
+}
+
+// Small tables (Kn*D <= 32768 floats): one block per 64 rows accumulates into an LDS-resident table.
+// Wave w owns the codes with (code & 3) == w and visits the chunk's rows in ascending order, so every table
+// entry has exactly one writer and a fixed summation order: deterministic, and independent of how skewed the
+// code usage is (a collapsed codebook no longer serialises one block).  Partials: part[blk][Kn*D + Kn].
+__global__ __launch_bounds__(256) void vq_segment_table_kernel(const float* __restrict__ rows, int ldr,
+                                                               const long long* __restrict__ idx, int R, int D, int k0,
+                                                               int Kn, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float table[];   // [Kn*D] sums, then [Kn] counts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = Kn * D;
+    for (int i = threadIdx.x; i < n + Kn; i += 256) table[i] = 0.f;
+    const int r0 = blockIdx.x * 64;
+    const int nrows = min(64, R - r0);
+    const int mycode = (lane < nrows) ? (int)(idx[r0 + lane] - k0) : -1;
+    __syncthreads();
+    for (int i0 = 0; i0 < nrows; i0 += 8) {
+        float v[8];
+        int code[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            code[u] = __shfl(mycode, min(i0 + u, 63), 64);
+            if (i0 + u >= nrows) code[u] = -1;
+        }
+        for (int col = lane; col < D; col += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (code[u] >= 0 && (code[u] & 3) == wave) ? rows[(size_t)(r0 + i0 + u) * ldr + col] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (code[u] >= 0 && (code[u] & 3) == wave) table[code[u] * D + col] += v[u];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (code[u] >= 0 && (code[u] & 3) == wave) table[n + code[u]] += 1.f;
+        }
+    }
+    __syncthreads();
+    float* out = part + (size_t)blockIdx.x * (n + Kn);
+    for (int i = threadIdx.x; i < n + Kn; i += 256) out[i] = table[i];
+}
+
+__global__ __launch_bounds__(1024) void vq_table_reduce_kernel(const float* __restrict__ part, int S, long long stride,
+                                                               long long n, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (i < n)
+        for (int k = ty; k < S; k += 16) s += part[(size_t)k * stride + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][tx];
+        out[i] = t;
+    }
 }
 
 // whole-table EMA refresh, arithmetic order of the reference (mul_, add_ of a scaled stat, divide)
@@ -296,10 +366,31 @@ extern "C" int vqh_vq_finish(const float* zq_levels, int Q, const float* ze, int
 
 // cnt[k0..k0+Kn), sum[k0..k0+Kn, :] are overwritten.
 extern "C" int vqh_vq_segment_sum(const float* rows, int ldr, const long long* idx, int R, int D, int k0, int Kn,
-                                  float* cnt, float* sum, hipStream_t stream) {
+                                  float* cnt, float* sum, float* workspace, long long workspace_floats,
+                                  hipStream_t stream) {
     VQH_CHECK_ARG(R >= 0 && D > 0 && D <= 1024 && Kn >= 0 && k0 >= 0, "vqh_vq_segment_sum: bad shape (D <= 1024)");
     if (Kn == 0) return VQH_OK;
     VQH_CHECK_ARG(rows && idx && cnt && sum, "vqh_vq_segment_sum: null pointer");
+    const long long tbl = (long long)Kn * D + Kn;
+    const int nblk = (R + 63) / 64;
+    if (workspace && tbl <= 36864 && nblk > 0 && tbl * nblk <= workspace_floats) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_segment_table_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(vq_segment_table_kernel, dim3(nblk), dim3(256), (size_t)tbl * sizeof(float), stream, rows, ldr,
+                           idx, R, D, k0, Kn, workspace);
+        const long long n = (long long)Kn * D;
+        hipLaunchKernelGGL(vq_table_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, stream, workspace, nblk,
+                           tbl, n, sum + (size_t)k0 * D);
+        hipLaunchKernelGGL(vq_table_reduce_kernel, dim3((Kn + 63) / 64), dim3(1024), 0, stream, workspace + n, nblk, tbl,
+                           (long long)Kn, cnt + k0);
+        VQH_LAUNCH_CHECK();
+        return VQH_OK;
+    }
 #define SEG(V) hipLaunchKernelGGL((vq_segment_sum_kernel<V>), dim3(Kn), dim3(256), 0, stream, rows, ldr, idx, R, D, k0, cnt, sum)
     if (D <= 64) SEG(1);
     else if (D <= 128) SEG(2);

@@ -447,7 +447,7 @@ class StepEngine:
             # per-code statistics of THIS level (other code ranges stay zero: the reference refreshes the whole table)
             call("vqh_memset", cnt, 0, K * 4)
             call("vqh_memset", ssum, 0, K * D * 4)
-            call("vqh_vq_segment_sum", rows, D, ids, R, D, lo, Kp, cnt, ssum)
+            call("vqh_vq_segment_sum", rows, D, ids, R, D, lo, Kp, cnt, ssum, self.ws, self.ws.numel())
             call("vqh_copy2d", cnt[lo:], Kp, usage[lo:], Kp, 1, Kp)
             if upd and defer:
                 # single level: this step's z_q already used the old table (:189 precedes :191-197), so the refresh
