@@ -53,6 +53,10 @@ int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, 
              float beta, const unsigned long long* rng_state, unsigned drop_site, float drop_p, float* workspace,
              long long workspace_floats, vqh_stream_t stream);
 
+/* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
+ * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads) */
+int vqh_gemm_set_flags(int flags);
+
 /* nn.LayerNorm forward/backward (eps 1e-5, biased variance); 35 instances on the path */
 int vqh_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, float* mean,
                       float* rstd, int rows, int H, float eps, vqh_stream_t stream);

@@ -45,6 +45,7 @@ struct GemmArgs {
     int lda, ldb, ldc;
     int kchunk;            // K range handled by one blockIdx.z (multiple of BK)
     int vecA, vecB;        // 16-byte vector loads legal for this operand
+    int vecC;              // 16-byte epilogue accesses legal (C, aux, bias aligned; ldc, ldaux multiples of 4)
     float* ws;             // split-K slabs [gridDim.z][M][N] (raw partial sums) or null
     // epilogue
     int mode;
@@ -54,6 +55,8 @@ struct GemmArgs {
     int ldaux;
     float beta;
     DropCfg drop;
+    int flags;             // tuning/diagnostic knobs (vqh_gemm_set_flags): 1 = XCD-aware tile order,
+                           // 2 = skip epilogue stores (timing only), 4 = skip global loads after the first tile (timing only)
 };
 
 __device__ __forceinline__ float epilogue_value(const GemmArgs& g, float acc, int row, int col,
@@ -172,7 +175,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
     const int l31 = lane & 31, h = lane >> 5;
 
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
+    int tile = blockIdx.x;
+    if (g.flags & 1) {
+        // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so that the
+        // tiles resident on one XCD share A panels / weight columns in that XCD's private L2 (bijective for any grid)
+        const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = tile & 7, j = tile >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
     const int kbeg = blockIdx.z * g.kchunk;
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
-        if (more) {
+        if (more && !(g.flags & 4)) {
             load_tile<A_KC>(g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BK, kend, g.vecA, tid, ra);
             load_tile<B_KC>(g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BK, kend, g.vecB, tid, rb);
         }
@@ -227,33 +236,96 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*h of each 32x32 tile ----
+    // ---- epilogue ----------------------------------------------------------------------------------
+    // Accumulator layout: lane owns column (lane&31), rows (r&3) + 8*(r>>2) + 4*h of each 32x32 tile, i.e.
+    // 4-byte accesses 128 B apart.  Stage the wave's 64x64 result through its (now idle) share of the LDS
+    // and let each lane handle 4 consecutive columns: 16-byte global stores / aux loads, 16 per lane
+    // instead of 64 (the scattered form ran at ~1 TB/s and cost ~30 % of a K=512 GEMM).
     unsigned long long seed = 0, step = 0;
     if (g.drop.p > 0.f && g.drop.rng_state) {
         seed = g.drop.rng_state[0];
         step = g.drop.rng_state[1];
     }
-    float* slab = g.ws ? g.ws + (size_t)blockIdx.z * g.M * g.N : nullptr;
+    if (g.flags & 2) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 123.456f) g.C[0] = s;   // keep the accumulators live
+        return;
+    }
+    constexpr int EP_LD = 68;                         // 64 + 4: conflict-free 4-byte writes, 16-byte aligned rows
+    float* ep = smem + wave * (64 * EP_LD);           // 4352 floats per wave <= A_TILE
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            if (col >= g.N) continue;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= g.M) continue;
-                if (slab) {
-                    slab[(size_t)row * g.N + col] = acc[i][j][r];
-                } else {
-                    float v = epilogue_value(g, acc[i][j][r], row, col, seed, step);
-                    float* c = g.C + (size_t)row * g.ldc + col;
-                    if (g.beta != 0.f) v += g.beta * (*c);
-                    *c = v;
+            for (int r = 0; r < 16; ++r)
+                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    float* slab = g.ws ? g.ws + (size_t)blockIdx.z * g.M * g.N : nullptr;
+    const int c4 = (lane & 15) * 4;
+    const int col = n0 + wn * 64 + c4;
+    const bool vecC = slab ? ((g.N & 3) == 0) : g.vecC;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + rl;
+        if (row >= g.M || col >= g.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * EP_LD + c4);
+        if (slab) {
+            float* dst = slab + (size_t)row * g.N + col;
+            if (vecC && col + 3 < g.N) *reinterpret_cast<f32x4*>(dst) = v;
+            else
+                for (int e = 0; e < 4; ++e) if (col + e < g.N) dst[e] = v[e];
+            continue;
+        }
+        const bool full = vecC && (col + 3 < g.N);
+        float* cptr = g.C + (size_t)row * g.ldc + col;
+        if (full) {
+            // ---- vector path: 4 consecutive columns
+            if (g.mode <= EPI_SIGMOID) {
+                if (g.bias) { const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col); v += bb; }
+                if (g.mode == EPI_RELU_DROP || g.mode == EPI_DROP_RESID) {
+                    if (g.mode == EPI_RELU_DROP)
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    if (g.drop.p > 0.f) {
+                        float f[4];
+                        drop4(g.drop, seed, step, ((unsigned long long)row * g.N + col) >> 2, f);
+                        for (int e = 0; e < 4; ++e) v[e] *= f[e];
+                    }
+                    if (g.mode == EPI_DROP_RESID) v += *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
+                } else if (g.mode == EPI_GELU) {
+                    *reinterpret_cast<f32x4*>(g.aux_out + (size_t)row * g.ldaux + col) = v;
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                } else if (g.mode == EPI_SIGMOID) {
+                    for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
                 }
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
+                if (g.mode == EPI_MUL_POSMASK)
+                    for (int e = 0; e < 4; ++e) v[e] = (a[e] > 0.f) ? v[e] * g.drop.scale : 0.f;
+                else if (g.mode == EPI_MUL_GELUGRAD)
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+                else
+                    for (int e = 0; e < 4; ++e) v[e] *= a[e] * (1.f - a[e]);
+            }
+            if (g.beta != 0.f) { const f32x4 old = *reinterpret_cast<const f32x4*>(cptr); v += g.beta * old; }
+            *reinterpret_cast<f32x4*>(cptr) = v;
+        } else {
+            for (int e = 0; e < 4; ++e) {
+                if (col + e >= g.N) break;
+                float x = epilogue_value(g, v[e], row, col + e, seed, step);
+                if (g.beta != 0.f) x += g.beta * cptr[e];
+                cptr[e] = x;
             }
         }
+    }
 }
 
 // Sum split-K slabs, add bias, C = beta*C + sum.  One thread per 4 consecutive columns.
@@ -293,6 +365,9 @@ int launch(const GemmArgs& g, int splits, hipStream_t stream) {
 
 }  // namespace
 
+static int g_gemm_flags = 1;
+extern "C" int vqh_gemm_set_flags(int flags) { const int old = g_gemm_flags; g_gemm_flags = flags; return old; }
+
 // C-ABI: see include/vqvae_hip.h for the contract.
 extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B,
                         int ldb, float* C, int ldc, const float* bias, int mode, const float* aux_in, float* aux_out,
@@ -316,15 +391,21 @@ extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     g.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+    {
+        uintptr_t al = reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(aux_in) |
+                       reinterpret_cast<uintptr_t>(aux_out);
+        g.vecC = ((al & 15) == 0 && (ldc & 3) == 0 && ((aux_in || aux_out) ? (ldaux & 3) == 0 : true) && (N & 3) == 0) ? 1 : 0;
+    }
     g.mode = mode; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.beta = beta;
     g.drop.rng_state = rng_state; g.drop.site = drop_site; g.drop.p = drop_p; g.drop.scale = 1.f / (1.f - drop_p);
     g.ws = nullptr;
+    g.flags = g_gemm_flags;
 
     // split-K when the output has too few tiles to fill 256 CUs (weight gradients: K = B*L rows).
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits = 1;
     if (workspace && mode == EPI_LINEAR && tiles < 256 && K >= 8 * BK) {
-        splits = (512 + tiles - 1) / tiles;
+        splits = 512 / tiles;                       // 2 resident blocks per CU x 256 CUs: no tail round
         const int max_by_k = K / (4 * BK);
         if (splits > max_by_k) splits = max_by_k;
         const long long per = (long long)M * N;
