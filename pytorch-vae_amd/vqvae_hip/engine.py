@@ -629,14 +629,14 @@ class StepEngine:
         call("vqh_adamw_step", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n_flat, self.hyper, self.norm)
 
     def world(self):
-        d = torch.distributed
-        return d.get_world_size() if (d.is_available() and d.is_initialized()) else 1
+        from .parallel import world_size
+        return world_size()
 
     def allreduce_grads(self):
         """ONE RCCL all-reduce (sum) over [gradients | EMA statistics]; the 1/world gradient average is folded
         into the clip coefficient (hyper[8]), the statistics are wanted as sums."""
-        if self.world() > 1:
-            torch.distributed.all_reduce(self.flat_gx if self._pending_ema is not None else self.flat_g)
+        from .parallel import allreduce_flat
+        allreduce_flat(self.flat_gx, include_stats=self._pending_ema is not None, n_grad=self.n_flat)
 
     # ------------------------------------------------------------------ fused training step
     def _step_part_a(self, x, mask, weights, upd):
@@ -690,18 +690,29 @@ class StepEngine:
         torch.cuda.synchronize()
         ga = torch.cuda.CUDAGraph()
         gb = None
-        if world == 1:
-            with torch.cuda.graph(ga):
-                self._step_part_a(xs, ms, weights, upd)
-                self._step_part_b()
-        else:
-            with torch.cuda.graph(ga):
-                self._step_part_a(xs, ms, weights, upd)
-            pend = self._pending_ema
-            gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb):
-                self._step_part_b()
-            self._pending_ema = pend
+        try:
+            # thread_local: the RCCL watchdog thread may query events while this thread captures
+            if world == 1:
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    self._step_part_a(xs, ms, weights, upd)
+                    self._step_part_b()
+            else:
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    self._step_part_a(xs, ms, weights, upd)
+                pend = self._pending_ema
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                    self._step_part_b()
+                self._pending_ema = pend
+        except Exception as e:          # capture refused (driver / collective state): stay on eager launches
+            print(f"[vqvae_hip] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
+            self._seen[key] = -(1 << 30)
+            self._pending_ema = None
+            torch.cuda.synchronize()
+            self._step_part_a(xs, ms, weights, upd)
+            self.allreduce_grads()
+            self._step_part_b()
+            return self.metrics
         self.graphs[key] = (ga, gb)
         ga.replay()
         if world > 1:

@@ -1,0 +1,42 @@
+# -*- coding: utf-8 -*-
+"""Data-parallel plumbing of the training step: one process per GPU, torch.distributed backend "nccl"
+(= RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The step has exactly ONE exchange: a sum all-reduce over the flat buffer [gradients | EMA statistics]
+  * gradients: DDP semantics (mean over ranks) -- the 1/world factor is folded into the clip coefficient
+    that the fused AdamW kernel already multiplies into every gradient (hyper[8]), so no extra pass;
+  * EMA statistics cnt[K] | sum[K,D]: wanted as SUMS over ranks, so that an N-rank step equals the
+    single-process step on the concatenated batch (the reference's DDP never reduces
+    them and broadcasts rank 0's codebook instead -- a documented, deliberate difference).
+The payload for config C2 is 172.5 MB + 0.13 MB, sent as one message: on xGMI (point-to-point links,
+7 x ~153 GB/s per GPU) a single large all-reduce is bandwidth-bound per link, many small ones are
+latency-bound."""
+import torch
+
+
+def world_size():
+    d = torch.distributed
+    return d.get_world_size() if (d.is_available() and d.is_initialized()) else 1
+
+
+def rank():
+    d = torch.distributed
+    return d.get_rank() if (d.is_available() and d.is_initialized()) else 0
+
+
+def shard_bounds(n, r=None, w=None):
+    """Contiguous, equal shard [lo, hi) of n samples for rank r of w (n must divide evenly: weak scaling)."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    if n % w:
+        raise ValueError(f"global batch {n} is not divisible by world size {w}")
+    per = n // w
+    return r * per, (r + 1) * per
+
+
+def allreduce_flat(flat, include_stats=True, n_grad=None):
+    """Sum-all-reduce `flat` (or only its first n_grad entries) in place; returns the gradient scale 1/world."""
+    w = world_size()
+    if w > 1:
+        torch.distributed.all_reduce(flat if (include_stats or n_grad is None) else flat[:n_grad])
+    return 1.0 / w

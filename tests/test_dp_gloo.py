@@ -1,0 +1,78 @@
+# -*- coding: utf-8 -*-
+"""world_size-2 data-parallel test on CPU (gloo): each rank computes gradients + EMA statistics of ITS shard with
+the oracle, packs them like the engine does ([grads | cnt | sum]), calls the product's allreduce_flat, and the
+result must equal the single-process computation on the concatenated batch (grads: mean, statistics: sum)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import gen_inputs as G
+from gen_inputs import O
+
+CFG = dict(G.SMALL_VQ)
+B, LQ, SEED = 8, 24, 404
+
+
+def _local(x, mask, weights):
+    cfg = O.make_cfg(**CFG)
+    sd = O.attach_grads(G.model_state(CFG, SEED), cfg)
+    orc = O.OracleVQVAE(sd, drop_scale=0.0, **CFG)
+    orc.training_steps = 1
+    emb0 = sd["quantizer.embedding"].clone()
+    out = orc.forward(x, mask)
+    ld = orc.loss_function(*out, **weights)
+    ld["loss"].backward()
+    grads = torch.cat([sd[k].grad.reshape(-1) for k in O.param_shapes(cfg)])
+    z_e, idx = out[2][1].detach().reshape(-1, cfg["code_dim"]), out[2][2].reshape(-1)
+    K = cfg["codebook_size"]
+    cnt = torch.zeros(K).index_add_(0, idx, torch.ones(idx.shape[0]))
+    ssum = torch.zeros(K, cfg["code_dim"]).index_add_(0, idx, z_e)
+    return grads, cnt, ssum, emb0
+
+
+def _worker(r, world, port, q):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-vae_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    torch.distributed.init_process_group("gloo", rank=r, world_size=world)
+    from vqvae_hip.parallel import allreduce_flat, shard_bounds, world_size
+    x, mask = G.curve_batch(B, LQ, SEED + 1, ragged=False)
+    lo, hi = shard_bounds(B)
+    g, cnt, ssum, _ = _local(x[lo:hi], mask[lo:hi], G.BASE_LOSS_WEIGHTS)
+    flat = torch.cat([g, cnt, ssum.reshape(-1)])
+    scale = allreduce_flat(flat)
+    assert world_size() == world and scale == 1.0 / world
+    if r == 0:
+        q.put(((flat[:g.numel()] * scale).numpy(), flat[g.numel():g.numel() + cnt.numel()].numpy().copy(),
+               flat[g.numel() + cnt.numel():].numpy().copy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_on_concatenated_batch():
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g2, cnt2, sum2 = (torch.from_numpy(a) for a in q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    x, mask = G.curve_batch(B, LQ, SEED + 1, ragged=False)
+    g1, cnt1, sum1, _ = _local(x, mask, G.BASE_LOSS_WEIGHTS)
+    assert torch.equal(cnt2, cnt1)                                   # integer counts: exactly additive
+    assert float((sum2.reshape(-1) - sum1.reshape(-1)).abs().max()) <= 1e-5 * float(sum1.abs().max())
+    assert float((g2 - g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+
+
+def test_shard_bounds():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-vae_amd"))
+    from vqvae_hip.parallel import shard_bounds
+    assert [shard_bounds(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 2048)]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 0, 4)

@@ -1,0 +1,73 @@
+# -*- coding: utf-8 -*-
+"""-m gpu: the engine's world_size>1 training-step path (graph split around the single all-reduce, deferred EMA
+refresh, 1/world folded into the clip coefficient) with 2 processes sharing cuda:0 over gloo.  After 3 steps
+(eager, capture, replay) the weights and the codebook must equal a single-process run on the concatenated batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import gen_inputs as G
+
+pytestmark = pytest.mark.gpu
+CFG = dict(G.SMALL_VQ)
+B, LQ, SEED, STEPS = 8, 24, 515, 3
+W = dict(G.BASE_LOSS_WEIGHTS, xyz_tv_lambda=0.001)
+
+
+def _run(x, mask, use_graph=True):
+    from models import vae_models
+    m = vae_models["VQVAE"](**CFG)
+    m.load_state_dict(G.model_state(CFG, SEED), strict=True)
+    m = m.to("cuda:0").train()
+    m.training_steps = 1
+    eng = m._engine()
+    eng.drop_scale = 0.0
+    for _ in range(STEPS):
+        m.train_step(x, mask, W, 1e-3, 0.01, 1.0, use_graph=use_graph)
+    torch.cuda.synchronize()
+    return ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, eng.metrics.cpu().clone())
+
+
+def _worker(r, world, port, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "pytorch-vae_amd"), os.path.join(here, "golden"), here):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=r, world_size=world)
+    from vqvae_hip.parallel import shard_bounds
+    x, mask = G.curve_batch(B, LQ, SEED + 1, ragged=False)
+    lo, hi = shard_bounds(B)
+    sd, met = _run(x[lo:hi].cuda(), mask[lo:hi].cuda())
+    if r == 0:
+        q.put({k: v.numpy() for k, v in sd.items()})      # by value: the producer may exit before the parent reads
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_train_steps_equal_single_process():
+    port = 29600 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sd2 = {k: torch.from_numpy(v) for k, v in q.get(timeout=600).items()}
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    x, mask = G.curve_batch(B, LQ, SEED + 1, ragged=False)
+    sd1, _ = _run(x.cuda(), mask.cuda())
+    sd1e, _ = _run(x.cuda(), mask.cuda(), use_graph=False)
+    for k in sd1:
+        if k.startswith("quantizer._ep_"):      # epoch usage diagnostics are per-rank (local shard) by design
+            continue
+        a, b, c = sd1[k].double(), sd2[k].double(), sd1e[k].double()
+        assert float((a - c).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), f"graph vs eager differ at {k}"
+        # first Adam steps move every weight by ~lr*sign(g): round-off-level gradients may flip, hence the lr-scale bound
+        assert float((a - b).abs().max()) <= 2.1e-3 * STEPS, k
+        assert float((a - b).abs().median()) <= 2e-5, k
+    assert torch.equal(sd1["quantizer.ema_cluster_size"], sd2["quantizer.ema_cluster_size"]) or \
+        float((sd1["quantizer.ema_cluster_size"] - sd2["quantizer.ema_cluster_size"]).abs().max()) < 1e-5

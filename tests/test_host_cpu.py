@@ -1,0 +1,245 @@
+# -*- coding: utf-8 -*-
+"""CPU suite for the host side: C-ABI consistency (header == sources == ctypes table == exported symbols),
+the model's drop-in surface (keys, seeded init, loud failure without a GPU), harness logic (schedules, LR
+policies, checkpoints, warm start) and an end-to-end plumbing run of config C1's harness with a CPU stand-in
+model (the oracle) -- the product model itself never runs on a CPU."""
+import ctypes
+import glob
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import gen_inputs as G
+from gen_inputs import O
+from conftest import load_golden, PKG, REPO
+from abi_util import header_protos
+
+
+# ---------------------------------------------------------------------------------------------- ABI
+def _src_protos():
+    def code(args):
+        c = ""
+        for a in args.split(","):
+            a = a.strip()
+            if not a or a == "void":
+                continue
+            if "*" in a or a.startswith("hipStream_t"):
+                c += "p"
+            elif a.startswith("long long"):
+                c += "l"
+            elif a.startswith("unsigned"):
+                c += "u"
+            elif a.startswith("float"):
+                c += "f"
+            elif a.startswith("int"):
+                c += "i"
+            else:
+                raise ValueError(a)
+        return c
+    out = {}
+    for f in glob.glob(os.path.join(PKG, "csrc", "*.hip")):
+        for m in re.finditer(r'extern "C"\s+(?:int|const char\*|void)\s+(vqh_\w+)\s*\(([^)]*)\)\s*\{', open(f).read()):
+            out[m.group(1)] = code(m.group(2))
+    return out
+
+
+def test_header_sources_and_ctypes_table_agree():
+    from vqvae_hip import lib
+    hdr, src = header_protos(), _src_protos()
+    for name, sig in hdr.items():
+        assert name in src, f"{name} declared in include/vqvae_hip.h but not defined"
+        assert src[name] == sig, f"{name}: header {sig} vs source {src[name]}"
+        if name in lib._PROTOS:
+            assert lib._PROTOS[name] == sig, f"{name}: ctypes table {lib._PROTOS[name]} vs header {sig}"
+    assert set(lib.EXPORTS) == set(hdr), set(lib.EXPORTS) ^ set(hdr)
+
+
+def test_shared_library_loads_and_exports_every_declared_symbol():
+    from vqvae_hip import lib
+    L = lib.lib()                      # dlopen only: no kernel is launched without a GPU
+    for name in header_protos():
+        assert hasattr(L, name), name
+    assert L.vqh_abi_version() == 1
+    assert isinstance(L.vqh_last_error(), bytes)
+
+
+# ---------------------------------------------------------------------------------------------- model surface
+def test_model_keys_and_seeded_init_equal_the_reference():
+    from models import vae_models, BaseVAE
+    for name, cfg, seed in (("init_small_vq_seed1265", G.SMALL_VQ, 1265), ("init_small_ae_seed7", G.SMALL_AE, 7)):
+        g = load_golden(name)
+        torch.manual_seed(seed)
+        m = vae_models["VQVAE"](**cfg)
+        sd = m.state_dict()
+        assert list(sd.keys()) == [str(k) for k in g["keys"]]
+        assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+        for k, want in zip(g["keys"], g["sums"]):
+            assert abs(G.checksum(sd[str(k)]) - float(want)) <= 1e-6 * max(1.0, abs(float(want))), k
+        assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    assert issubclass(BaseVAE, torch.nn.Module)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_model_fails_loudly_without_gpu():
+    from models import vae_models
+    from vqvae_hip.lib import VqhError
+    m = vae_models["VQVAE"](**G.SMALL_VQ)
+    with pytest.raises(VqhError):
+        m(torch.zeros(1, 8, 6), torch.ones(1, 8, dtype=torch.bool))
+    with pytest.raises(VqhError):
+        m.decode(torch.zeros(1, 8, 16))
+
+
+def test_constructor_swallows_unknown_kwargs_and_validates_centroids():
+    from models import vae_models
+    m = vae_models["VQVAE"](name="anything", **G.SMALL_VQ)
+    with pytest.raises(ValueError):
+        m.init_codebook_from_centroids(torch.zeros(3, 16))
+    with pytest.raises(ValueError):
+        m.init_codebook_from_centroids(torch.zeros(2, 16, 8))
+    m.init_codebook_from_centroids(torch.ones(32, 16))
+    assert float(m.quantizer.ema_cluster_size.min()) == 1.0 and float(m.quantizer.embedding.mean()) == 1.0
+    m.beta = 0.125
+    assert m.quantizer.beta == 0.125
+
+
+# ---------------------------------------------------------------------------------------------- harness logic
+def test_interpolate_schedule_known_answers():
+    from experiment import interpolate_schedule
+    s = {"a": [[0, 0.0], [10, 1.0], [20, 3.0]], "b": [[5, 2.0]], "empty": []}
+    assert interpolate_schedule(s, 0) == {"a": 0.0, "b": 2.0}
+    assert interpolate_schedule(s, 5)["a"] == pytest.approx(0.5)
+    assert interpolate_schedule(s, 10)["a"] == pytest.approx(1.0)
+    assert interpolate_schedule(s, 15)["a"] == pytest.approx(2.0)
+    assert interpolate_schedule(s, 20)["a"] == 3.0 and interpolate_schedule(s, 999)["a"] == 3.0
+    assert interpolate_schedule(s, 7)["b"] == 2.0
+    assert interpolate_schedule({}, 3) == {} and interpolate_schedule(None, 3) == {}
+    cfg = yaml.safe_load(open(os.path.join(PKG, "configs", "stage2_vq.yaml")))
+    v = interpolate_schedule(cfg["exp_params"]["schedules"], 100)
+    assert v["beta"] == pytest.approx(0.005 + (100 - 80) / 60 * 0.001)
+    assert v["LR"] == pytest.approx(0.0002 - (100 - 30) / 150 * 0.0001)
+
+
+def test_lr_policies_match_torch_schedulers():
+    from experiment import LRPolicy
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=0.004)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.004, epochs=3, steps_per_epoch=7, pct_start=0.12, anneal_strategy="cos",
+                                              div_factor=20.0, final_div_factor=5000.0)
+    pol = LRPolicy("onecycle", 0.004, max_epochs=3, steps_per_epoch=7, pct_start=0.12, div_factor=20.0, final_div=5000.0)
+    for _ in range(21):
+        lr, b1 = pol.current()
+        assert lr == pytest.approx(opt.param_groups[0]["lr"], rel=1e-9)
+        assert b1 == pytest.approx(opt.param_groups[0]["betas"][0], rel=1e-9)
+        opt.step()
+        if _ < 20:
+            sch.step()
+        pol.on_step()
+    opt = torch.optim.AdamW([p], lr=0.01)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=9, eta_min=0.01 * 1e-6)
+    pol = LRPolicy("cosine", 0.01, max_epochs=9)
+    for _ in range(9):
+        assert pol.current()[0] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-6)
+        opt.step(); sch.step(); pol.on_epoch()
+
+
+def test_pad_collate_and_synthetic_dataset():
+    from dataset import pad_collate, SyntheticCurveDataset
+    ds = SyntheticCurveDataset(5, max_len=12, min_len=4, seed=3)
+    items = [ds[i] for i in range(5)]
+    x, mask = pad_collate(items)
+    assert x.shape == (5, max(t.shape[0] for t in items), 6) and mask.dtype == torch.bool
+    for i, t in enumerate(items):
+        assert int(mask[i].sum()) == t.shape[0] and torch.equal(x[i, :t.shape[0]], t) and float(x[i, t.shape[0]:].abs().sum()) == 0
+        assert float(t[:, :3].mean(0).abs().max()) < 1e-5 and torch.all(t[:, 3:].sum(-1) == 1)
+    assert torch.equal(ds[2], ds[2])
+    with pytest.raises(RuntimeError):
+        pad_collate([])
+
+
+class _CpuStandIn:
+    """Test-only stand-in with the harness-facing interface of models.VQVAE, computing with the oracle.
+    Exists so the harness (schedules, LR policy, checkpoints, epoch hooks) can be exercised without a GPU."""
+
+    def __init__(self, **mp):
+        self.cfg = O.make_cfg(**mp)
+        self.sd = O.attach_grads(O.random_state(self.cfg, 5), self.cfg)
+        self.orc = O.OracleVQVAE(self.sd, drop_scale=0.0, **mp)
+        self.opt = torch.optim.AdamW(self.orc.params(), lr=1e-3)
+        self.use_vq = self.cfg["use_vq"]
+        self.quantizer = None
+        self.label_smoothing = self.usage_entropy_lambda = 0.0
+        self._beta = 0.0
+        self.sums = torch.zeros(24)
+        self.training = True
+        self.steps = 0
+
+    beta = property(lambda s: s._beta, lambda s, v: setattr(s, "_beta", float(v)))
+
+    def to(self, *_a, **_k): return self
+    def train(self, mode=True): self.training = mode; self.orc.training = mode; return self
+    def eval(self): return self.train(False)
+    def state_dict(self): return {k: v.detach() for k, v in self.sd.items()}
+    def load_state_dict(self, sd, strict=True):
+        with torch.no_grad():
+            for k, v in sd.items():
+                self.sd[k].copy_(v)
+        return [], []
+    def metric_names(self):
+        from vqvae_hip.engine import METRIC_KEYS
+        return list(METRIC_KEYS)
+    def metric_sums(self): return self.sums
+    def reset_metric_sums(self): self.sums.zero_()
+    def _vec(self, ld):
+        return torch.tensor([float(ld.get(k, 0.0)) for k in self.metric_names()])
+    def train_step(self, x, mask, weights, lr, wd, clip, betas=(0.9, 0.999), use_graph=True):
+        for g in self.opt.param_groups:
+            g["lr"], g["weight_decay"], g["betas"] = lr, wd, betas
+        ld, _, _ = self.orc.train_step(x, mask, self.opt, clip, weights)
+        self.steps += 1
+        v = self._vec(ld); self.sums += v
+        return v
+    def eval_step(self, x, mask, weights):
+        with torch.no_grad():
+            out = self.orc.forward(x, mask)
+            return self._vec(self.orc.loss_function(*out, **weights))
+
+
+def test_c1_harness_plumbing_two_epochs_on_cpu(tmp_path):
+    """Config C1 (stage1_ae.yaml harness, synthetic 64-long curves, bs=8, 2 epochs) with the CPU stand-in."""
+    from experiment import VQVAEExperiment
+    from trainer import Trainer, ModelCheckpoint
+    cfg = yaml.safe_load(open(os.path.join(PKG, "configs", "stage1_ae.yaml")))
+    mp = dict(cfg["model_params"], hidden_dim=64, num_heads=4, tokenizer_heads=4, num_layers=1, code_dim=16, latent_tokens=8,
+              max_seq_len=64, print_init=False)
+    dp = dict(cfg["data_params"], train_batch_size=8, val_batch_size=8, num_workers=0, pin_memory=False,
+              synthetic={"n": 32, "n_val": 8, "max_len": 64, "min_len": 40, "seed": 1})
+    exp = VQVAEExperiment(mp, cfg["exp_params"], dp, model_cls=_CpuStandIn)
+    tr = Trainer(max_epochs=2, gradient_clip_val=1.0, accelerator="cpu", limit_val_batches=1.0,
+                 callbacks=[ModelCheckpoint(str(tmp_path), filename="epoch{epoch:03d}", every_n_epochs=1)])
+    tr.fit(exp)
+    assert exp.model.steps == 8 and exp.global_step == 8 and exp.lr_policy.kind == "onecycle"
+    assert exp.current_weights["ss_weight"] == pytest.approx(0.60 + 0.25 / 8)          # schedule at epoch 1
+    assert exp.current_weights["xyz_tv_lambda"] == pytest.approx(0.006 + 0.0004)
+    assert "epoch/loss" in exp.logged and np.isfinite(exp.logged["epoch/loss"])
+    ck = torch.load(os.path.join(str(tmp_path), "last.ckpt"), map_location="cpu", weights_only=True)
+    assert ck["epoch"] == 1 and all(k.startswith("model.") for k in ck["state_dict"])
+    assert set(k[6:] for k in ck["state_dict"]) == set(exp.model.state_dict().keys())
+    # resume: epoch counter, LR policy position and weights come back
+    exp2 = VQVAEExperiment(mp, cfg["exp_params"], dp, model_cls=_CpuStandIn)
+    tr2 = Trainer(max_epochs=3, gradient_clip_val=1.0, accelerator="cpu", limit_val_batches=0)
+    tr2.fit(exp2, ckpt_path=os.path.join(str(tmp_path), "last.ckpt"))
+    assert exp2.model.steps == 4 and exp2.lr_policy.step_num == 12 and tr2.current_epoch == 2
+
+
+def test_warm_start_filter_drops_quantizer_and_shape_mismatches():
+    from experiment import VQVAEExperiment
+    cand = {"model.a": torch.zeros(2), "model.quantizer.embedding": torch.zeros(3), "model.b": torch.zeros(5), "model.zz": torch.zeros(1)}
+    st = VQVAEExperiment._strip_model_prefix(cand)
+    kept, sp, ss = VQVAEExperiment._filter_state_dict_for_warmstart(st, {"a": torch.zeros(2), "b": torch.zeros(4), "quantizer.embedding": torch.zeros(3)})
+    assert list(kept) == ["a"] and sp == ["quantizer.embedding"] and ss == ["b"]
