@@ -175,16 +175,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
     const int l31 = lane & 31, h = lane >> 5;
 
     const int tiles_n = (g.N + BN - 1) / BN;
-    int tile = blockIdx.x;
+    int tile = blockIdx.x, zsplit = blockIdx.z;
     if (g.flags & 1) {
-        // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so that the
-        // tiles resident on one XCD share A panels / weight columns in that XCD's private L2 (bijective for any grid)
-        const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = tile & 7, j = tile >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        // Workgroups are dealt round-robin to the 8 XCDs in linear-id order (x fastest, then z), so ids b and b+8
+        // share an XCD.  Give each XCD a contiguous run of (split, tile) pairs: tiles that share A panels / weight
+        // columns -- and, for split-K, all tiles of one K-chunk -- then hit the same private L2 (bijective for any grid).
+        const int nx = gridDim.x, nt = nx * gridDim.z, lin = blockIdx.z * nx + blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, x = lin & 7, j = lin >> 3;
+        const int v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        tile = v % nx;
+        zsplit = v / nx;
     }
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int kbeg = zsplit * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
 
     f32x16 acc[2][2];
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
                 ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[i][j][r];
     __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
-    float* slab = g.ws ? g.ws + (size_t)blockIdx.z * g.M * g.N : nullptr;
+    float* slab = g.ws ? g.ws + (size_t)zsplit * g.M * g.N : nullptr;
     const int c4 = (lane & 15) * 4;
     const int col = n0 + wn * 64 + c4;
     const bool vecC = slab ? ((g.N & 3) == 0) : g.vecC;

@@ -111,6 +111,81 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// float4 variant: lane owns float4 groups q = lane + 64*j (H % 4 == 0, 16-byte aligned rows); 1 KiB per wave
+// instruction instead of 256 B.  Same slab layout as the scalar kernel.
+template <int NV>  // float4 groups per lane: H <= 256*NV
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, int lddy,
+                                                                const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ dx,
+                                                                int lddx, int accumulate, float* __restrict__ part,
+                                                                int rows, int H) {
+    __shared__ float red[WAVES_PER_BLOCK][2][256 * NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = H >> 2;
+    f32x4 aw[NV], ab[NV], wv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        aw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int q = lane + 64 * j;
+        wv[j] = (q < nq) ? *reinterpret_cast<const f32x4*>(w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float invH = 1.f / (float)H;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wave; row < rows; row += gridDim.x * WAVES_PER_BLOCK) {
+        const float* dyr = dy + (size_t)row * lddy;
+        const float* xr = x + (size_t)row * ldx;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = lane + 64 * j;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+            if (q < nq) {
+                d = *reinterpret_cast<const f32x4*>(dyr + 4 * q);
+                xv = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+                xv = (xv - mu) * rs;
+            }
+            xh[j] = xv;
+            g[j] = d * wv[j];
+            aw[j] += d * xv;
+            ab[j] += d;
+            const f32x4 gx = g[j] * xv;
+            s1 += (g[j][0] + g[j][1]) + (g[j][2] + g[j][3]);
+            s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+        }
+        s1 = wave_sum(s1) * invH;
+        s2 = wave_sum(s2) * invH;
+        float* dxr = dx + (size_t)row * lddx;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = lane + 64 * j;
+            if (q < nq) {
+                f32x4 v = (g[j] - s1 - xh[j] * s2) * rs;
+                if (accumulate) v += *reinterpret_cast<const f32x4*>(dxr + 4 * q);
+                *reinterpret_cast<f32x4*>(dxr + 4 * q) = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][0][4 * (lane + 64 * j) + e] = aw[j][e];
+            red[wave][1][4 * (lane + 64 * j) + e] = ab[j][e];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * H; i += 256) {
+        const int which = i / H, c = i % H;
+        float s = 0.f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < WAVES_PER_BLOCK; ++wv_) s += red[wv_][which][c];
+        part[((size_t)blockIdx.x * 2 + which) * H + c] = s;
+    }
+}
+
 // out[i] = beta*out[i] + sum_s slabs[s*stride + i]
 // block = 64 columns x 16 slab lanes: every thread sums S/16 slabs with independent loads, the 16 partials of
 // a column are combined through LDS in a fixed order (deterministic).
@@ -143,6 +218,31 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 // column sums: part[blk][n] = sum over the block's rows of X[m][n]   (bias / broadcast-param grads)
 // block (64 columns x 4 row lanes); grid (ceil(N/64), row_blocks)
 // ------------------------------------------------------------------------------------------
+// float4 variant: block = 64 float4 column groups (256 columns) x 4 row lanes; grid (ceil(N/256), row_blocks)
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ X, int ld, int M, int N,
+                                                         float* __restrict__ part, int rows_per_block) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (c < N) {
+        int r = r0 + ry;
+        for (; r + 4 < r1; r += 8) {
+            s0 += *reinterpret_cast<const f32x4*>(X + (size_t)r * ld + c);
+            s1 += *reinterpret_cast<const f32x4*>(X + (size_t)(r + 4) * ld + c);
+        }
+        for (; r < r1; r += 4) s0 += *reinterpret_cast<const f32x4*>(X + (size_t)r * ld + c);
+    }
+    red[ry][lane] = s0 + s1;
+    __syncthreads();
+    if (ry == 0 && c < N) {
+        const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * N + c) = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, int M, int N,
                                                      float* __restrict__ part, int rows_per_block) {
     __shared__ float red[4][64];
@@ -312,8 +412,19 @@ extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int 
     if (rows == 0) return VQH_OK;
     VQH_CHECK_ARG(dy && x && w && mean && rstd && dx && dw && db && workspace, "vqh_layernorm_bwd: null pointer");
     int nblk = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    if (nblk > 512) nblk = 512;
+    if (nblk > 1024) nblk = 1024;
     VQH_CHECK_ARG((long long)nblk * 2 * H <= workspace_floats, "vqh_layernorm_bwd: workspace too small");
+    const bool vec = (H % 4 == 0) && H <= 1024 && ((lddy | ldx | lddx) % 4 == 0) &&
+                     (((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                        reinterpret_cast<uintptr_t>(w)) & 15) == 0);
+#define LN_BWD_V(V)                                                                                                    \
+    hipLaunchKernelGGL((layernorm_bwd_vec_kernel<V>), dim3(nblk), dim3(256), 0, stream, dy, lddy, x, ldx, w, mean, rstd, \
+                       dx, lddx, accumulate_dx, workspace, rows, H)
+    if (vec) {
+        if (H <= 256) LN_BWD_V(1);
+        else if (H <= 512) LN_BWD_V(2);
+        else LN_BWD_V(4);
+    } else
 #define LN_BWD(V)                                                                                                  \
     hipLaunchKernelGGL((layernorm_bwd_kernel<V>), dim3(nblk), dim3(256), 0, stream, dy, lddy, x, ldx, w, mean, rstd, \
                        dx, lddx, accumulate_dx, workspace, rows, H)
@@ -324,6 +435,7 @@ extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int 
     else if (H <= 1024) LN_BWD(16);
     else LN_BWD(32);
 #undef LN_BWD
+#undef LN_BWD_V
     VQH_LAUNCH_CHECK();
     // slab layout [blk][2][H]: dw = sum_blk slab[blk][0], db = sum_blk slab[blk][1]
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, workspace, nblk, (long long)2 * H,
@@ -345,7 +457,10 @@ extern "C" int vqh_colsum(const float* X, int ld, int M, int N, float* out, floa
     if (rb > 128) rb = 128;
     const int rows_per_block = (M + rb - 1) / rb > 0 ? (M + rb - 1) / rb : 1;
     VQH_CHECK_ARG((long long)rb * N <= workspace_floats, "vqh_colsum: workspace too small");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, rb), dim3(256), 0, stream, X, ld, M, N, workspace, rows_per_block);
+    if ((N & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0)
+        hipLaunchKernelGGL(colsum_vec_kernel, dim3((N + 255) / 256, rb), dim3(256), 0, stream, X, ld, M, N, workspace, rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, rb), dim3(256), 0, stream, X, ld, M, N, workspace, rows_per_block);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, workspace, rb, (long long)N,
                        (long long)N, out, beta);
     VQH_LAUNCH_CHECK();
