@@ -5,14 +5,15 @@
 // DecoderLayer self- and cross-attention built at :458-473, :525-528): scores scaled by 1/sqrt(dh),
 // additive -inf key-padding mask, softmax over keys, dropout on the probabilities, P.V.
 //
-// One wave = one (batch, head, 32-row tile).  Orientation trick: the score tile is computed
+// One wave = one (batch, head, 32-row tile); two waves per workgroup share LDS-staged operand tiles.  Orientation trick: the score tile is computed
 // TRANSPOSED, S^T[key][query] = K.Q^T, so that in the MFMA accumulator a lane owns one QUERY column
 // and its registers run over KEYS.  Then
 //   * softmax max / sum over keys are register reductions + one cross-half shuffle,
 //   * the probabilities are already laid out as the B operand (k = key) of the next product
 //     O^T[d][query] += V^T[d][key] . P^T[key][query]  -- no LDS, no lane movement.
-// Operands come straight from global/L2 (tiles are a few KB and shared by neighbouring waves);
-// the 16-byte fragment loads use the same k-permutation for both operands (see gemm.hip).
+// The streamed operand (K/V, or Q/dO in the key-side backward kernel) is staged 64 rows at a time through LDS
+// with coalesced 16-byte loads; the 16-byte fragment reads use the same k-permutation for both MFMA operands
+// (see gemm.hip).
 #include "common.h"
 
 namespace {
@@ -42,12 +43,38 @@ struct AttnArgs {
     float* dV; int lddv;
 };
 
+// ---- attention dropout stream ----------------------------------------------------------------------
+// Element (b, head, q, key) has index ((b*nh + head)*T + q) * S4 + key with S4 = S rounded up to 4, so four
+// consecutive keys of one query are ONE Philox evaluation (drop4).  In the query-major kernels a lane holds
+// keys 8g+4h .. +3 of its query in registers 4g..4g+3: one evaluation per register group.
+__device__ __forceinline__ int round4(int s) { return (s + 3) & ~3; }
+
+// ---- LDS staging -------------------------------------------------------------------------------
+// A block = 2 waves = 64 rows of one (batch, head).  The other operand (K/V for the query-side kernels, Q/dO
+// for the key-side kernel) is staged 64 rows at a time into LDS with coalesced 16-byte loads issued in bulk,
+// then every MFMA fragment comes from LDS:  [row][DH+4] floats (row stride == 4 mod 64 dwords: the 16-lane
+// groups of ds_read_b128 cover all 64 banks; the transposed operand reads 32 consecutive dwords per half).
 template <int DH>
-__global__ __launch_bounds__(64, 2) void attn_fwd_kernel(const AttnArgs a) {
-    constexpr int NG = DH / 8, ND = (DH + 31) / 32;
-    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 32, hh = blockIdx.y, b = blockIdx.z;
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int ld, int row0,
+                                           int nrows_total, int tid) {
+    constexpr int LD = DH + 4, C4 = DH / 4;
+    for (int i = tid; i < 64 * C4; i += 128) {
+        const int r = i / C4, c = (i % C4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < nrows_total) v = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + r) * ld + c);
+        *reinterpret_cast<f32x4*>(dst + r * LD + c) = v;
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(128, 2) void attn_fwd_kernel(const AttnArgs a) {
+    constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 64 + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
+    const bool active = q0 < a.T;
     const float* Qp = a.Q + ((size_t)b * a.T + q) * a.ldq + hh * DH;
     const float* Kb = a.K + (size_t)b * a.S * a.ldk + hh * DH;
     const float* Vb = a.V + (size_t)b * a.S * a.ldv + hh * DH;
@@ -68,55 +95,72 @@ __global__ __launch_bounds__(64, 2) void attn_fwd_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m = -INFINITY, lsum = 0.f;
 
-    for (int s0 = 0; s0 < a.S; s0 += 32) {
-        f32x16 sacc;
+    for (int c0 = 0; c0 < a.S; c0 += 64) {
+        __syncthreads();
+        stage_rows<DH>(Ks, Kb, a.ldk, c0, a.S, tid);
+        stage_rows<DH>(Vs, Vb, a.ldv, c0, a.S, tid);
+        __syncthreads();
+        if (!active) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        const int key_l = s0 + l31;
+        for (int sub = 0; sub < 2; ++sub) {
+            const int s0 = c0 + sub * 32;
+            if (s0 >= a.S) break;
+            f32x16 sacc;
 #pragma unroll
-        for (int t = 0; t < NG; ++t) {
-            const f32x4 kf = ld4_guard(Kb + (size_t)key_l * a.ldk + 8 * t + 4 * h, key_l < a.S);
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const float* kr = Ks + (sub * 32 + l31) * LD + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], sacc, 0, 0, 0);
-        }
-        float mx = -INFINITY;
-        bool ok[16];
+            for (int t = 0; t < NG; ++t) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + 8 * t);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = s0 + kmap(r, h);
-            ok[r] = (key < a.S) && (!kv || kv[key]);
-            if (ok[r]) mx = fmaxf(mx, sacc[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);
-        const float corr = (m_new == -INFINITY) ? 1.f : __expf(m - m_new);
-        float psum = 0.f;
-        float p[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = ok[r] ? __expf(sacc[r] - m_new) : 0.f;
-            psum += p[r];
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        lsum = lsum * corr + psum;
-        m = m_new;
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= corr;
-        if (a.drop.p > 0.f) {
-            const unsigned long long base = (((unsigned long long)b * a.nh + hh) * a.T + q) * (unsigned long long)a.S;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] *= drop1(a.drop, seed, step, base + (unsigned long long)(s0 + kmap(r, h)));
-        }
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int dcol = d * 32 + l31;
+                for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], sacc, 0, 0, 0);
+            }
+            // validity of the tile's 32 keys as a bit mask: one coalesced byte load + ballot, no divergent branches
+            const int keyl = s0 + l31;
+            const unsigned char vb = (kv && keyl < a.S) ? kv[keyl] : (unsigned char)1;
+            const unsigned int vmask = (unsigned int)__ballot((keyl < a.S) && vb != 0);
+            float mx = -INFINITY;
+            bool ok[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = s0 + kmap(r, h);
-                const float vv = (key < a.S && dcol < DH) ? Vb[(size_t)key * a.ldv + dcol] : 0.f;
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[r], o[d], 0, 0, 0);
+                ok[r] = (vmask >> kmap(r, h)) & 1u;
+                mx = ok[r] ? fmaxf(mx, sacc[r]) : mx;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float corr = (m_new == -INFINITY) ? 1.f : __expf(m - m_new);
+            float psum = 0.f;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = ok[r] ? __expf(sacc[r] - m_new) : 0.f;
+                psum += p[r];
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            lsum = lsum * corr + psum;
+            m = m_new;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+            if (a.drop.p > 0.f) {
+                const unsigned long long base = (((unsigned long long)b * a.nh + hh) * a.T + q) * (unsigned long long)round4(a.S);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float f[4];
+                    drop4(a.drop, seed, step, (base + (unsigned long long)(s0 + 8 * g4 + 4 * h)) >> 2, f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[4 * g4 + e] *= f[e];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int dcol = d * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float vv = (dcol < DH) ? Vs[(sub * 32 + kmap(r, h)) * LD + dcol] : 0.f;
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[r], o[d], 0, 0, 0);
+                }
             }
         }
     }
@@ -134,14 +178,16 @@ __global__ __launch_bounds__(64, 2) void attn_fwd_kernel(const AttnArgs a) {
     }
 }
 
-// dQ (and D = rowsum(dO*O)) : one wave per 32 queries, loop over key tiles.
+// dQ (and D = rowsum(dO*O)) : one wave per 32 queries (2 per block), K/V staged through LDS.
 template <int DH>
-__global__ __launch_bounds__(64, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
-    constexpr int NG = DH / 8, ND = (DH + 31) / 32;
-    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 32, hh = blockIdx.y, b = blockIdx.z;
+__global__ __launch_bounds__(128, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+    constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 64 + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
-    const bool qok = q < a.T;
+    const bool qok = q < a.T, active = q0 < a.T;
     const float* Qp = a.Q + ((size_t)b * a.T + q) * a.ldq + hh * DH;
     const float* dOp = a.dO + ((size_t)b * a.T + q) * a.lddo + hh * DH;
     const float* Op = a.O + ((size_t)b * a.T + q) * a.ldo + hh * DH;
@@ -172,40 +218,58 @@ __global__ __launch_bounds__(64, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-    for (int s0 = 0; s0 < a.S; s0 += 32) {
-        f32x16 sacc, dpacc;
+    for (int c0 = 0; c0 < a.S; c0 += 64) {
+        __syncthreads();
+        stage_rows<DH>(Ks, Kb, a.ldk, c0, a.S, tid);
+        stage_rows<DH>(Vs, Vb, a.ldv, c0, a.S, tid);
+        __syncthreads();
+        if (!active) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-        const int key_l = s0 + l31;
+        for (int sub = 0; sub < 2; ++sub) {
+            const int s0 = c0 + sub * 32;
+            if (s0 >= a.S) break;
+            f32x16 sacc, dpacc;
 #pragma unroll
-        for (int t = 0; t < NG; ++t) {
-            const f32x4 kf = ld4_guard(Kb + (size_t)key_l * a.ldk + 8 * t + 4 * h, key_l < a.S);
-            const f32x4 vf = ld4_guard(Vb + (size_t)key_l * a.ldv + 8 * t + 4 * h, key_l < a.S);
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            const float* kr = Ks + (sub * 32 + l31) * LD + 4 * h;
+            const float* vr = Vs + (sub * 32 + l31) * LD + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], sacc, 0, 0, 0);
-                dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[t][j], dpacc, 0, 0, 0);
+            for (int t = 0; t < NG; ++t) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + 8 * t);
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(vr + 8 * t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[t][j], dpacc, 0, 0, 0);
+                }
             }
-        }
-        float ds[16];
-        const unsigned long long base = (((unsigned long long)b * a.nh + hh) * a.T + q) * (unsigned long long)a.S;
+            float ds[16], keep[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = s0 + kmap(r, h);
-            const bool ok = (key < a.S) && (!kv || kv[key]);
-            const float p = ok ? __expf(sacc[r] - lse) : 0.f;
-            float keep = 1.f;
-            if (a.drop.p > 0.f) keep = drop1(a.drop, seed, step, base + (unsigned long long)key);
-            ds[r] = p * (dpacc[r] * keep - dsum);
-        }
+            for (int r = 0; r < 16; ++r) keep[r] = 1.f;
+            if (a.drop.p > 0.f) {
+                const unsigned long long base = (((unsigned long long)b * a.nh + hh) * a.T + q) * (unsigned long long)round4(a.S);
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int dcol = d * 32 + l31;
+                for (int g4 = 0; g4 < 4; ++g4)
+                    drop4(a.drop, seed, step, (base + (unsigned long long)(s0 + 8 * g4 + 4 * h)) >> 2, &keep[4 * g4]);
+            }
+            const int keyl = s0 + l31;
+            const unsigned char vb = (kv && keyl < a.S) ? kv[keyl] : (unsigned char)1;
+            const unsigned int vmask = (unsigned int)__ballot((keyl < a.S) && vb != 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = s0 + kmap(r, h);
-                const float kk = (key < a.S && dcol < DH) ? Kb[(size_t)key * a.ldk + dcol] : 0.f;
-                dq[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, ds[r], dq[d], 0, 0, 0);
+                const bool ok = (vmask >> kmap(r, h)) & 1u;
+                const float pe = __expf(fminf(sacc[r] - lse, 80.f));
+                const float p = ok ? pe : 0.f;
+                ds[r] = p * (dpacc[r] * keep[r] - dsum);
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int dcol = d * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float kk = (dcol < DH) ? Ks[(sub * 32 + kmap(r, h)) * LD + dcol] : 0.f;
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, ds[r], dq[d], 0, 0, 0);
+                }
             }
         }
     }
@@ -221,13 +285,17 @@ __global__ __launch_bounds__(64, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
 }
 
-// dK, dV : one wave per 32 keys, loop over query tiles (needs Dsum from the dQ kernel).
+// dK, dV : one wave per 32 keys (2 per block); Q / dO / LSE / D of 64 queries at a time staged through LDS.
 template <int DH>
-__global__ __launch_bounds__(64, 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
-    constexpr int NG = DH / 8, ND = (DH + 31) / 32;
-    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
-    const int s0 = blockIdx.x * 32, hh = blockIdx.y, b = blockIdx.z;
+__global__ __launch_bounds__(128, 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
+    __shared__ __attribute__((aligned(16))) float Qs[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Os[64 * LD];
+    __shared__ float Ls[64], Ds[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int s0 = blockIdx.x * 64 + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int key = s0 + l31;
+    const bool active = s0 < a.S;
     const float* Qb = a.Q + (size_t)b * a.T * a.ldq + hh * DH;
     const float* dOb = a.dO + (size_t)b * a.T * a.lddo + hh * DH;
     const float* Kp = a.K + ((size_t)b * a.S + key) * a.ldk + hh * DH;
@@ -250,61 +318,110 @@ __global__ __launch_bounds__(64, 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
 
     const size_t rowbase = ((size_t)b * a.nh + hh) * a.T;
-    for (int q0 = 0; q0 < a.T; q0 += 32) {
-        f32x16 sacc, dpacc;
+    for (int c0 = 0; c0 < a.T; c0 += 64) {
+        __syncthreads();
+        stage_rows<DH>(Qs, Qb, a.ldq, c0, a.T, tid);
+        stage_rows<DH>(Os, dOb, a.lddo, c0, a.T, tid);
+        if (tid < 64) {
+            const int qq = c0 + tid;
+            Ls[tid] = (qq < a.T) ? a.LSE[rowbase + qq] : 0.f;
+            Ds[tid] = (qq < a.T) ? a.Dsum[rowbase + qq] : 0.f;
+        }
+        __syncthreads();
+        if (!active) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-        const int q_l = q0 + l31;
+        for (int sub = 0; sub < 2; ++sub) {
+            const int q0 = c0 + sub * 32;
+            if (q0 >= a.T) break;
+            f32x16 sacc, dpacc;
 #pragma unroll
-        for (int t = 0; t < NG; ++t) {
-            f32x4 qf = ld4_guard(Qb + (size_t)q_l * a.ldq + 8 * t + 4 * h, q_l < a.T);
-            qf *= a.scale;
-            const f32x4 dof = ld4_guard(dOb + (size_t)q_l * a.lddo + 8 * t + 4 * h, q_l < a.T);
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            const float* qr = Qs + (sub * 32 + l31) * LD + 4 * h;
+            const float* orow = Os + (sub * 32 + l31) * LD + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[t][j], sacc, 0, 0, 0);
-                dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[j], vf[t][j], dpacc, 0, 0, 0);
+            for (int t = 0; t < NG; ++t) {
+                f32x4 qf = *reinterpret_cast<const f32x4*>(qr + 8 * t);
+                qf *= a.scale;
+                const f32x4 dof = *reinterpret_cast<const f32x4*>(orow + 8 * t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[t][j], sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[j], vf[t][j], dpacc, 0, 0, 0);
+                }
             }
-        }
-        float pd[16], ds[16];
+            float pd[16], ds[16], keep[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + kmap(r, h);
-            const bool ok = kok && (q < a.T);
-            float lse = 0.f, dsum = 0.f;
-            if (q < a.T) { lse = a.LSE[rowbase + q]; dsum = a.Dsum[rowbase + q]; }
-            const float p = ok ? __expf(sacc[r] - lse) : 0.f;
-            float keep = 1.f;
-            if (a.drop.p > 0.f && ok)
-                keep = drop1(a.drop, seed, step, ((unsigned long long)(rowbase + q)) * (unsigned long long)a.S + key);
-            pd[r] = p * keep;
-            ds[r] = p * (dpacc[r] * keep - dsum);
-        }
+            for (int r = 0; r < 16; ++r) keep[r] = 1.f;
+            if (a.drop.p > 0.f) {
+                // registers 4g..4g+3 hold queries qg..qg+3 (qg = c0 + sub*32 + 8g + 4h) for THIS lane's key.  Lane i = key&3
+                // evaluates Philox for (query qg+i, key quad of its 4-lane group); round k hands component j=(key&3) of the
+                // evaluation owned by lane (j+k)&3 to lane j: 4 evaluations + 4 shuffles per group instead of 16 evaluations.
+                const int i4 = l31 & 3;
+                const unsigned long long S4 = (unsigned long long)round4(a.S);
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int dcol = d * 32 + l31;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int qmine = c0 + sub * 32 + 8 * g4 + 4 * h + i4;
+                    float f[4];
+                    drop4(a.drop, seed, step, (((unsigned long long)(rowbase + qmine)) * S4 + (unsigned long long)(key & ~3)) >> 2, f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int want = (i4 - k) & 3;          // component the receiver (i4 - k) & 3 needs from me
+                        float send = f[0];
+                        send = (want == 1) ? f[1] : send;
+                        send = (want == 2) ? f[2] : send;
+                        send = (want == 3) ? f[3] : send;
+                        const float got = __shfl(send, (lane & ~3) | ((i4 + k) & 3), 64);
+                        const int e = (i4 + k) & 3;             // the query row this value belongs to
+                        keep[4 * g4 + 0] = (e == 0) ? got : keep[4 * g4 + 0];
+                        keep[4 * g4 + 1] = (e == 1) ? got : keep[4 * g4 + 1];
+                        keep[4 * g4 + 2] = (e == 2) ? got : keep[4 * g4 + 2];
+                        keep[4 * g4 + 3] = (e == 3) ? got : keep[4 * g4 + 3];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int q = q0 + kmap(r, h);
-                const bool in = (q < a.T) && (dcol < DH);
-                const float dov = in ? dOb[(size_t)q * a.lddo + dcol] : 0.f;
-                const float qv = in ? Qb[(size_t)q * a.ldq + dcol] : 0.f;
-                dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(dov, pd[r], dv[d], 0, 0, 0);
-                dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[r], dk[d], 0, 0, 0);
+                const int ql = sub * 32 + kmap(r, h);
+                const int q = c0 + ql;
+                const bool ok = kok && (q < a.T);
+                const float pe = __expf(fminf(sacc[r] - Ls[ql], 80.f));   // evaluated unconditionally: no divergent branch
+                const float p = ok ? pe : 0.f;
+                pd[r] = p * keep[r];
+                ds[r] = p * (dpacc[r] * keep[r] - Ds[ql]);
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int dcol = d * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = sub * 32 + kmap(r, h);
+                    const float dov = (dcol < DH) ? Os[ql * LD + dcol] : 0.f;
+                    const float qv = (dcol < DH) ? Qs[ql * LD + dcol] : 0.f;
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(dov, pd[r], dv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[r], dk[d], 0, 0, 0);
+                }
             }
         }
     }
     if (kin) {
         float* dKp = a.dK + ((size_t)b * a.S + key) * a.lddk + hh * DH;
         float* dVp = a.dV + ((size_t)b * a.S + key) * a.lddv + hh * DH;
+        const bool vec = ((a.lddk | a.lddv) & 3) == 0 && (((reinterpret_cast<uintptr_t>(a.dK) | reinterpret_cast<uintptr_t>(a.dV)) & 15) == 0);
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dd = d * 32 + kmap(r, h);
-                if (dd < DH) {
-                    dKp[dd] = dk[d][r] * a.scale;
-                    dVp[dd] = dv[d][r];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * h;          // registers 4g..4g+3 = 4 consecutive columns
+                if (dd >= DH) continue;
+                f32x4 kk, vv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { kk[e] = dk[d][4 * g4 + e] * a.scale; vv[e] = dv[d][4 * g4 + e]; }
+                if (vec) {
+                    *reinterpret_cast<f32x4*>(dKp + dd) = kk;
+                    *reinterpret_cast<f32x4*>(dVp + dd) = vv;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { dKp[dd + e] = kk[e]; dVp[dd + e] = vv[e]; }
                 }
             }
     }
@@ -328,11 +445,11 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE;
     a.kvalid = kvalid; a.B = B; a.nh = nh; a.T = T; a.S = S; a.scale = 1.0f / sqrtf((float)dh);
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
-    dim3 grid((T + 31) / 32, nh, B);
+    dim3 grid((T + 63) / 64, nh, B);
     switch (dh) {
-        case 16: hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(64), 0, stream, a); break;
-        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64), 0, stream, a); break;
-        default: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64), 0, stream, a); break;
+        case 16: hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(128), 0, stream, a); break;
+        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(128), 0, stream, a); break;
+        default: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(128), 0, stream, a); break;
     }
     VQH_LAUNCH_CHECK();
     return VQH_OK;
@@ -357,19 +474,19 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     a.scale = 1.0f / sqrtf((float)dh);
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
     a.dO = dO; a.lddo = lddo; a.Dsum = Dsum; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
-    dim3 gq((T + 31) / 32, nh, B), gk((S + 31) / 32, nh, B);
+    dim3 gq((T + 63) / 64, nh, B), gk((S + 63) / 64, nh, B);
     switch (dh) {
         case 16:
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, gq, dim3(64), 0, stream, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<16>, gk, dim3(64), 0, stream, a);
+            hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, gq, dim3(128), 0, stream, a);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<16>, gk, dim3(128), 0, stream, a);
             break;
         case 32:
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(64), 0, stream, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(64), 0, stream, a);
+            hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(128), 0, stream, a);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(128), 0, stream, a);
             break;
         default:
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(64), 0, stream, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64), 0, stream, a);
+            hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(128), 0, stream, a);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(128), 0, stream, a);
             break;
     }
     VQH_LAUNCH_CHECK();

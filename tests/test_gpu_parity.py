@@ -161,6 +161,35 @@ def test_attention_dropout_consistent_between_forward_and_backward():
     assert float((o - o2).abs().max()) > 1e-3          # dropout really changed the output
 
 
+def test_attention_dropout_gradients_match_autograd_with_extracted_mask():
+    """Recover the kernel's dropout mask (V = identity makes O = P*keep), then check dQ/dK/dV against torch autograd
+    evaluated with that explicit mask: forward, dQ kernel and dK/dV kernel must all regenerate the same Philox mask."""
+    L = _hip()
+    torch.manual_seed(4)
+    B, nh, T, S, dh, p = 2, 2, 40, 16, 16, 0.3
+    E = nh * dh
+    q, k, do = torch.randn(B, T, E, device=DEV), torch.randn(B, S, E, device=DEV), torch.randn(B, T, E, device=DEV)
+    rng = torch.tensor([7, 5], device=DEV, dtype=torch.int64)
+    eye = torch.eye(S, dh, device=DEV).repeat(1, nh)[None].repeat(B, 1, 1).contiguous()      # V[b, s, head*dh + d] = (s == d)
+    o, o0, lse = torch.empty(B, T, E, device=DEV), torch.empty(B, T, E, device=DEV), torch.empty(B * nh * T, device=DEV)
+    L.call("vqh_attn_fwd", q, E, k, E, eye, E, o, E, lse, None, B, nh, T, S, dh, rng, 3, p)
+    L.call("vqh_attn_fwd", q, E, k, E, eye, E, o0, E, lse, None, B, nh, T, S, dh, None, 0, 0.0)
+    keep = (o / o0).view(B, T, nh, dh).transpose(1, 2)[..., :S]                                # [B, nh, T, S] in {0, 1/(1-p)}
+    assert abs(float((keep == 0).float().mean()) - p) < 0.05
+    assert float(((keep - 1 / (1 - p)).abs() < 1e-4).float().mean() + (keep == 0).float().mean()) > 0.999
+    v = torch.randn(B, S, E, device=DEV)
+    L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, None, B, nh, T, S, dh, rng, 3, p)
+    dq, dk, dv, dsum = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty(B * nh * T, device=DEV)
+    L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, None, B, nh, T, S, dh, rng, 3, p)
+    qd, kd, vd = (t.double().cpu().requires_grad_(True) for t in (q, k, v))
+    sc = (qd.view(B, T, nh, dh).transpose(1, 2) @ kd.view(B, S, nh, dh).transpose(1, 2).transpose(-1, -2)) / math.sqrt(dh)
+    pm = torch.softmax(sc, -1) * keep.double().cpu().round(decimals=6)
+    ref = (pm @ vd.view(B, S, nh, dh).transpose(1, 2)).transpose(1, 2).reshape(B, T, E)
+    ref.backward(do.double().cpu())
+    assert rel(o, ref) < 1e-5
+    assert rel(dq, qd.grad) < 2e-5 and rel(dk, kd.grad) < 2e-5 and rel(dv, vd.grad) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # quantizer against the golden vectors recorded from the reference
 # ------------------------------------------------------------------------------------------------
