@@ -107,6 +107,9 @@ int vqh_vq_segment_sum(const float* rows, int ldr, const long long* idx, int R, 
                        float* sum, float* workspace, long long workspace_floats, vqh_stream_t stream);
 int vqh_vq_ema_apply(const float* cnt, const float* sum, float* ema_cnt, float* ema_emb, float* emb, int K, int D,
                      float decay, float one_minus_decay, float eps, vqh_stream_t stream);
+/* _maybe_reinit_dead_codes (models/vq_vae.py:91-107): codes with usage <= threshold take row pick[k] of `rows` */
+int vqh_vq_reinit(const float* usage, float threshold, const long long* pick, const float* rows, int ldr, float* emb,
+                  float* ema_emb, float* ema_cnt, int K, int D, vqh_stream_t stream);
 int vqh_vq_usage_stats(const float* usage, int K, float n_positions, float* ep_usage, float* ep_cnt, float* stats,
                        vqh_stream_t stream);
 

@@ -22,9 +22,13 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int KC_LD = BK + 4;            // padded row of a k-contiguous LDS image
-constexpr int A_TILE = BM * KC_LD;       // floats per operand tile buffer (upper bound of both layouts)
+constexpr int BM = 128, BN = 128;
+constexpr int BK = 32;                   // granularity of split-K chunks (both kernel variants divide it)
+template <int BKT> struct Tile {
+    static constexpr int KC_LD = BKT + 4;           // padded row of a k-contiguous LDS image
+    static constexpr int A_TILE = BM * KC_LD;       // floats per operand tile buffer (upper bound of both layouts)
+    static constexpr int NLD = BKT / 8;             // float4 loads per thread and operand tile
+};
 
 enum EpiMode {
     EPI_LINEAR = 0,        // v = acc + bias
@@ -95,15 +99,17 @@ __device__ __forceinline__ float epilogue_value(const GemmArgs& g, float acc, in
 // Load this thread's share (4 x float4) of one operand tile into registers.
 //   KC  : tile element (r, k) lives at src[(row0 + r) * ld + k]
 //   !KC : tile element (r, k) lives at src[k * ld + row0 + r]
-template <bool KC>
+template <bool KC, int BKT>
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int rows, int row0, int k0,
-                                          int kend, bool vec, int tid, f32x4 (&regs)[4]) {
+                                          int kend, bool vec, int tid, f32x4 (&regs)[BKT / 8]) {
+    constexpr int CPR = BKT / 4;            // float4 chunks per k-contiguous row
+    constexpr int RPI = 256 / CPR;          // rows covered per pass
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BKT / 8; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (KC) {
-            const int r = row0 + (tid >> 3) + 32 * i;
-            const int k = k0 + (tid & 7) * 4;
+            const int r = row0 + (tid / CPR) + RPI * i;
+            const int k = k0 + (tid % CPR) * 4;
             if (r < rows) {
                 const float* p = src + (size_t)r * ld + k;
                 if (vec && k + 3 < kend) {
@@ -132,13 +138,14 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld,
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const f32x4 (&regs)[4]) {
+template <bool KC, int BKT>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const f32x4 (&regs)[BKT / 8]) {
+    constexpr int CPR = BKT / 4, RPI = 256 / CPR, KC_LD = BKT + 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BKT / 8; ++i) {
         if (KC) {
-            const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<f32x4*>(lds + r * KC_LD + (tid & 7) * 4) = regs[i];
+            const int r = (tid / CPR) + RPI * i;
+            *reinterpret_cast<f32x4*>(lds + r * KC_LD + (tid % CPR) * 4) = regs[i];
         } else {
             const int k = (tid >> 5) + 8 * i;
             *reinterpret_cast<f32x4*>(lds + k * BM + (tid & 31) * 4) = regs[i];
@@ -147,8 +154,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, con
 }
 
 // Fragment for MFMA group t (k = 8t .. 8t+7): 4 values per lane, value j belongs to k = 8t + 4h + j.
-template <bool KC>
+template <bool KC, int BKT>
 __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int row, int t, int h) {
+    constexpr int KC_LD = BKT + 4;
     if (KC) {
         return *reinterpret_cast<const f32x4*>(lds + row * KC_LD + 8 * t + 4 * h);
     } else {
@@ -162,8 +170,9 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int ro
     }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
+template <bool A_KC, bool B_KC, int BKT>
+__global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const GemmArgs g) {
+    constexpr int A_TILE = Tile<BKT>::A_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // stage s: A tile at smem + 2*s*A_TILE, B tile right behind it
 #define AS(s) (smem + (s) * 2 * A_TILE)
@@ -199,13 +208,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[4], rb[4];
-    const int nk = (kend - kbeg + BK - 1) / BK;
+    f32x4 ra[BKT / 8], rb[BKT / 8];
+    const int nk = (kend - kbeg + BKT - 1) / BKT;
     if (nk > 0) {
-        load_tile<A_KC>(g.A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
-        load_tile<B_KC>(g.B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
-        store_tile<A_KC>(AS(0), tid, ra);
-        store_tile<B_KC>(BS(0), tid, rb);
+        load_tile<A_KC, BKT>(g.A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
+        load_tile<B_KC, BKT>(g.B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
+        store_tile<A_KC, BKT>(AS(0), tid, ra);
+        store_tile<B_KC, BKT>(BS(0), tid, rb);
     }
     __syncthreads();
 
@@ -213,18 +222,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
         if (more && !(g.flags & 4)) {
-            load_tile<A_KC>(g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BK, kend, g.vecA, tid, ra);
-            load_tile<B_KC>(g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BK, kend, g.vecB, tid, rb);
+            load_tile<A_KC, BKT>(g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BKT, kend, g.vecA, tid, ra);
+            load_tile<B_KC, BKT>(g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BKT, kend, g.vecB, tid, rb);
         }
         const float* a_s = AS(cur);
         const float* b_s = BS(cur);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < BKT / 8; ++t) {
             f32x4 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_KC>(a_s, wm * 64 + i * 32 + l31, t, h);
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_KC, BKT>(a_s, wm * 64 + i * 32 + l31, t, h);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_KC>(b_s, wn * 64 + j * 32 + l31, t, h);
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_KC, BKT>(b_s, wn * 64 + j * 32 + l31, t, h);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -234,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            store_tile<A_KC>(AS(cur ^ 1), tid, ra);
-            store_tile<B_KC>(BS(cur ^ 1), tid, rb);
+            store_tile<A_KC, BKT>(AS(cur ^ 1), tid, ra);
+            store_tile<B_KC, BKT>(BS(cur ^ 1), tid, rb);
         }
         __syncthreads();
     }
@@ -261,25 +270,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
         if (s == 123.456f) g.C[0] = s;   // keep the accumulators live
         return;
     }
-    constexpr int EP_LD = 68;                         // 64 + 4: conflict-free 4-byte writes, 16-byte aligned rows
-    float* ep = smem + wave * (64 * EP_LD);           // 4352 floats per wave <= A_TILE
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
-    __builtin_amdgcn_wave_barrier();
+    constexpr int EP_LD = 64;                         // 32-row half tile per wave: 8 KiB, conflict-free both ways
+    float* ep = smem + wave * (32 * EP_LD);
     float* slab = g.ws ? g.ws + (size_t)zsplit * g.M * g.N : nullptr;
     const int c4 = (lane & 15) * 4;
     const int col = n0 + wn * 64 + c4;
     const bool vecC = slab ? ((g.N & 3) == 0) : g.vecC;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[half][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 8; ++it) {
         const int rl = it * 4 + (lane >> 4);
-        const int row = m0 + wm * 64 + rl;
+        const int row = m0 + wm * 64 + half * 32 + rl;
         if (row >= g.M || col >= g.N) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * EP_LD + c4);
         if (slab) {
@@ -330,6 +340,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
 }
 
 // Sum split-K slabs, add bias, C = beta*C + sum.  One thread per 4 consecutive columns.
@@ -347,12 +359,12 @@ __global__ void splitk_reduce(const float* __restrict__ ws, int S, int M, int N,
     }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int BKT>
 int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     static bool attr_set = false;
-    const size_t smem = (size_t)4 * A_TILE * sizeof(float);
+    const size_t smem = (size_t)4 * Tile<BKT>::A_TILE * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<A_KC, B_KC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<A_KC, B_KC, BKT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             vqh_set_error(hipGetErrorString(e));
@@ -362,7 +374,7 @@ int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles, 1, splits);
-    hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC>), grid, dim3(256), smem, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC, BKT>), grid, dim3(256), smem, stream, g);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
@@ -424,10 +436,17 @@ extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const
     if (splits > 1) g.ws = workspace;
 
     int rc;
-    if (a_kcontig && b_kcontig) rc = launch<true, true>(g, splits, stream);
-    else if (a_kcontig && !b_kcontig) rc = launch<true, false>(g, splits, stream);
-    else if (!a_kcontig && b_kcontig) rc = launch<false, true>(g, splits, stream);
-    else rc = launch<false, false>(g, splits, stream);
+    if (g.flags & 8) {          // BK=16 variant: 41 KB of LDS, 3 workgroups per CU
+        if (a_kcontig && b_kcontig) rc = launch<true, true, 16>(g, splits, stream);
+        else if (a_kcontig && !b_kcontig) rc = launch<true, false, 16>(g, splits, stream);
+        else if (!a_kcontig && b_kcontig) rc = launch<false, true, 16>(g, splits, stream);
+        else rc = launch<false, false, 16>(g, splits, stream);
+    } else {
+        if (a_kcontig && b_kcontig) rc = launch<true, true, 32>(g, splits, stream);
+        else if (a_kcontig && !b_kcontig) rc = launch<true, false, 32>(g, splits, stream);
+        else if (!a_kcontig && b_kcontig) rc = launch<false, true, 32>(g, splits, stream);
+        else rc = launch<false, false, 32>(g, splits, stream);
+    }
     if (rc != VQH_OK) return rc;
     if (splits > 1) {
         const size_t total = (size_t)M * N;

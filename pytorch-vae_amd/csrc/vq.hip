@@ -310,6 +310,22 @@ __global__ __launch_bounds__(256) void vq_usage_stats_kernel(const float* __rest
     }
 }
 
+// dead-code re-seeding (reference _maybe_reinit_dead_codes, models/vq_vae.py:91-107): every code whose batch usage
+// is <= threshold takes a random encoder row: embedding = ema_embedding = z_e[pick[k]], ema_cluster_size = 1
+__global__ void vq_reinit_kernel(const float* __restrict__ usage, float threshold, const long long* __restrict__ pick,
+                                 const float* __restrict__ rows, int ldr, float* __restrict__ emb,
+                                 float* __restrict__ ema_emb, float* __restrict__ ema_cnt, int K, int D) {
+    const int k = blockIdx.x;
+    if (k >= K || !(usage[k] <= threshold)) return;
+    const float* src = rows + (size_t)pick[k] * ldr;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        const float v = src[c];
+        emb[(size_t)k * D + c] = v;
+        ema_emb[(size_t)k * D + c] = v;
+    }
+    if (threadIdx.x == 0) ema_cnt[k] = 1.f;
+}
+
 inline int blocks_for(long long n) {
     long long b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -419,6 +435,15 @@ extern "C" int vqh_vq_usage_stats(const float* usage, int K, float n_positions, 
                                   float* stats, hipStream_t stream) {
     VQH_CHECK_ARG(K > 0 && usage && stats, "vqh_vq_usage_stats: bad argument");
     hipLaunchKernelGGL(vq_usage_stats_kernel, dim3(1), dim3(256), 0, stream, usage, K, n_positions, ep_usage, ep_cnt, stats);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_vq_reinit(const float* usage, float threshold, const long long* pick, const float* rows, int ldr,
+                             float* emb, float* ema_emb, float* ema_cnt, int K, int D, hipStream_t stream) {
+    VQH_CHECK_ARG(K > 0 && D > 0 && usage && pick && rows && emb && ema_emb && ema_cnt, "vqh_vq_reinit: bad argument");
+    hipLaunchKernelGGL(vq_reinit_kernel, dim3(K), dim3(64), 0, stream, usage, threshold, pick, rows, ldr, emb, ema_emb,
+                       ema_cnt, K, D);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }

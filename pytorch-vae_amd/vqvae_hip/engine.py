@@ -463,6 +463,37 @@ class StepEngine:
         call("vqh_vq_usage_stats", usage, K, float(Q * R), q._ep_usage, q._ep_cnt, self.vq_stats)
         return z_st, z_q, idx, self.vq_stats
 
+    def maybe_reinit_dead_codes(self):
+        """Trigger of VQVAE.forward (models/vq_vae.py:874-891) + VectorQuantizerEMA._maybe_reinit_dead_codes (:91-107).
+        Runs eagerly after the step (the step's z_q was gathered before, so only later steps see the new codes).
+        One host sync every 500 steps, like the reference's `.item()`.  With several ranks, rank 0's re-seeded
+        buffers are broadcast (the reference's DDP broadcasts rank 0's buffers every forward)."""
+        m, q = self.m, self.m.quantizer
+        if q is None or not self.train:
+            return False
+        step = m.training_steps
+        if not (step % 500 == 0 and step >= max(m.ema_update_freeze_steps, 800)):
+            return False
+        if step < m.ema_update_freeze_steps or not q.reinit_dead_codes or q.reinit_prob <= 0.0:
+            return False
+        usage = self.buf["vq.usage"]
+        if self.world() > 1:
+            usage = usage.clone()
+            torch.distributed.all_reduce(usage)
+        n_dead = int((usage <= float(q.dead_usage_threshold)).sum().item())
+        R = self.buf["tok.z_e"].shape[0]
+        if n_dead <= 0 or R == 0:
+            return False
+        if float(torch.rand(())) > q.reinit_prob:
+            return False
+        pick = torch.randint(0, R, (q.K,), device=self.dev)
+        call("vqh_vq_reinit", usage, float(q.dead_usage_threshold), pick, self.buf["tok.z_e"], self.D, q.embedding,
+             q.ema_embedding, q.ema_cluster_size, q.K, self.D)
+        if self.world() > 1:
+            for t in (q.embedding, q.ema_embedding, q.ema_cluster_size):
+                torch.distributed.broadcast(t, 0)
+        return True
+
     def apply_ema(self, decay):
         q = self.m.quantizer
         K, D = q.K, q.D
@@ -541,6 +572,8 @@ class StepEngine:
         upd = self._host_prologue()
         out = self._forward_core(x, mask, upd)
         self.finish_ema()
+        if upd:
+            self.maybe_reinit_dead_codes()
         return out
 
     def _host_prologue(self):
@@ -651,6 +684,12 @@ class StepEngine:
         call("vqh_add", self.metrics_acc, self.metrics, self.metrics_acc, self.metrics.numel())
 
     def train_step(self, x, mask, weights, lr, weight_decay, clip, use_graph=True):
+        out = self._train_step(x, mask, weights, lr, weight_decay, clip, use_graph)
+        if self.m.use_vq and self.m.training_steps % 500 == 0:
+            self.maybe_reinit_dead_codes()
+        return out
+
+    def _train_step(self, x, mask, weights, lr, weight_decay, clip, use_graph=True):
         """One whole training step (experiment.py:453 training_step + Lightning backward/clip/AdamW) on the GPU.
         Steady state = hipGraph replays; results land in self.metrics (device).  The captured graph holds every
         kernel of the step; for world_size > 1 it is split around the single RCCL all-reduce."""

@@ -42,6 +42,7 @@ _PROTOS = {
     "vqh_vq_segment_sum": "pipiiiippplp",
     "vqh_vq_ema_apply": "pppppiifffp",
     "vqh_vq_usage_stats": "pifpppp",
+    "vqh_vq_reinit": "pfppipppiip",
     "vqh_loss_fwd_bwd": "pppipppiiiiipppppplp",
     "vqh_grad_norm": "plpppp",
     "vqh_adamw_step": "pppplppp",

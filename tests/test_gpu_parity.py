@@ -362,6 +362,41 @@ def test_true_width_c2_model_b2_matches_reference_golden():
     assert np.allclose(gne, g["gradnorm_each_0"], rtol=3e-3, atol=2e-6 * float(g["grad_norm_0"]))
 
 
+def test_dead_code_reinit_semantics():
+    """models/vq_vae.py:91-107: codes with batch usage <= threshold are re-seeded from encoder rows (embedding and
+    ema_embedding equal to one of the z_e rows, ema_cluster_size = 1); live codes are untouched; gated by
+    step % 500 == 0 and step >= max(freeze, 800)."""
+    from models.vq_vae import VQVAE
+    cfg = dict(G.SMALL_VQ, reinit_dead_codes=True, reinit_prob=1.0, dead_usage_threshold=0)
+    m = VQVAE(**cfg)
+    m.load_state_dict(G.model_state(cfg, 9), strict=True)
+    m = m.to(DEV).train()
+    eng = m._engine()
+    eng.drop_scale = 0.0
+    x, mask = G.curve_batch(6, 24, 10, ragged=True)
+    m.training_steps = 998                      # forward makes it 999: no re-init
+    m(x.to(DEV), mask.to(DEV))
+    before = m.quantizer.embedding.clone()
+    m(x.to(DEV), mask.to(DEV))                  # step 1000: trigger
+    usage = eng.buf["vq.usage"].clone()
+    dead = usage <= 0
+    assert int(dead.sum()) > 0
+    ze = eng.buf["tok.z_e"]
+    q = m.quantizer
+    for k in torch.nonzero(dead).flatten().tolist():
+        hit = (ze == q.embedding[k]).all(dim=1)
+        assert bool(hit.any()) and torch.equal(q.embedding[k], q.ema_embedding[k]) and float(q.ema_cluster_size[k]) == 1.0
+    m2 = VQVAE(**dict(cfg, reinit_dead_codes=False))
+    m2.load_state_dict(G.model_state(cfg, 9), strict=True)
+    m2 = m2.to(DEV).train()
+    m2._engine().drop_scale = 0.0
+    m2.training_steps = 998
+    m2(x.to(DEV), mask.to(DEV)); m2(x.to(DEV), mask.to(DEV))
+    live = ~dead
+    assert torch.equal(q.embedding[live], m2.quantizer.embedding[live])      # live codes identical to a run without re-init
+    assert not torch.equal(q.embedding[dead], m2.quantizer.embedding[dead])
+
+
 def test_adamw_and_clip_match_torch():
     L = _hip()
     torch.manual_seed(5)
