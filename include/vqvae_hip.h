@@ -86,6 +86,17 @@ int vqh_add(const float* a, const float* b, float* out, long long n, vqh_stream_
 int vqh_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, vqh_stream_t stream);
 int vqh_sigmoid_bwd(const float* dy, const float* y, float* out, long long n, vqh_stream_t stream);
 
+/* input-only rigid augmentation + coordinate noise (models/vq_vae.py:775-792; u,t,noise device tensors or NULL) */
+int vqh_augment(const float* x, const float* u, const float* t, const float* noise, float* out, int B, int L,
+                vqh_stream_t stream);
+/* P = softmax(scale*S + colbias) per row, in place: soft-VQ probabilities (:838-841), usage-entropy logits (:1305-1306) */
+int vqh_softmax_rows(float* S, int ld, const float* colbias, float scale, int R, int K, vqh_stream_t stream);
+int vqh_softmax_bwd_colgrad(float* P, int ld, const float* g, int R, int K, vqh_stream_t stream);
+int vqh_usage_entropy_finish(const float* colsum, int K, int R, float lambda, float* g, float* metrics, int i_loss,
+                             int i_reg, vqh_stream_t stream);
+int vqh_vq_mix(const float* ze, const float* zsoft, const float* zhard, float alpha, float* out, long long n,
+               vqh_stream_t stream);
+
 /* nn.MultiheadAttention core (scaled scores, key padding mask, softmax, dropout, P.V), flash style.
  * Q/K/V/O element (b, t, head, d) at ptr[(b*T + t)*ld + head*dh + d]; kvalid [B,S] bytes (1 = attend) or NULL. */
 int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
@@ -107,6 +118,7 @@ int vqh_vq_segment_sum(const float* rows, int ldr, const long long* idx, int R, 
                        float* sum, float* workspace, long long workspace_floats, vqh_stream_t stream);
 int vqh_vq_ema_apply(const float* cnt, const float* sum, float* ema_cnt, float* ema_emb, float* emb, int K, int D,
                      float decay, float one_minus_decay, float eps, vqh_stream_t stream);
+int vqh_row_sqnorm(const float* X, int ld, int rows, int D, float* out, float scale, vqh_stream_t stream);
 /* _maybe_reinit_dead_codes (models/vq_vae.py:91-107): codes with usage <= threshold take row pick[k] of `rows` */
 int vqh_vq_reinit(const float* usage, float threshold, const long long* pick, const float* rows, int ldr, float* emb,
                   float* ema_emb, float* ema_cnt, int K, int D, vqh_stream_t stream);
@@ -116,6 +128,7 @@ int vqh_vq_usage_stats(const float* usage, int K, float n_positions, float* ep_u
 /* VQVAE.loss_function forward + gradient w.r.t. recons / z_e (models/vq_vae.py:1097-1388).
  * weights[16] = {rmsd_w, ss_w, bond_length_w, bond_angle_w, dir_w, dih_w, xyz_tv_lambda, pdm_w, win_kabsch_w,
  *                kappa_w, tau_w, lr_pdm_w, xyz_align_alpha, ss_tv_lambda, label_smoothing, beta}   (HOST pointer)
+ * data_stats  = NULL or 6 HOST floats {std xyz, mean xyz} of set_data_stats() (:568-574, to_real :1218-1227)
  * iparams[6]  = {pdm_window, win_kabsch_size, win_kabsch_stride, lr_min_sep, lr_stride, lr_max_offsets} (HOST)
  * metrics[24] (device): loss, Reconstruction_Loss_XYZ, XYZ_MSE_Raw, XYZ_MSE_Aligned, Reconstruction_Loss_SS,
  *   SS_Accuracy, VQ_Loss, Geom_BondLength_Loss, Geom_BondAngle_Loss, Geom_Direction_Loss, Geom_Dihedral_Loss,
@@ -123,8 +136,8 @@ int vqh_vq_usage_stats(const float* usage, int K, float n_positions, float* ep_u
  *   Geom_WinKabsch, Frenet_Kappa, Frenet_Tau, Geom_LongRangePDM */
 int vqh_loss_fwd_bwd(const float* recons, const float* target, const unsigned char* mask, int masked, const float* ze,
                      const float* zq, const float* vq_stats, int B, int L, int Ntok, int D, int use_vq,
-                     const float* weights, const int* iparams, float* d_recons, float* d_ze, float* metrics,
-                     float* workspace, long long workspace_floats, vqh_stream_t stream);
+                     const float* weights, const int* iparams, const float* data_stats, float* d_recons, float* d_ze,
+                     float* metrics, float* workspace, long long workspace_floats, vqh_stream_t stream);
 
 /* clip_grad_norm_ + torch.optim.AdamW over flat buffers (experiment.py:170, run.py:191-197).
  * hyper (device, 9 floats): lr, beta1, beta2, eps, weight_decay, max_norm, 1-beta1^t, 1-beta2^t,

@@ -404,6 +404,28 @@ class OracleVQVAE:
             z_dec, z_q = z_e, z_e
             idx = torch.zeros(z_e.shape[0], z_e.shape[1], dtype=torch.long)
             ppl = dead = torch.tensor(0.0)
+        elif c["soft_vq_use"] and self.training and self.Q == 1:
+            # soft-VQ (:828-861): value-only mixture of the soft and hard codes, EMA update on the hard indices
+            upd = self.training and (self.training_steps >= c["ema_update_freeze_steps"])
+            B_, N_, D_ = z_e.shape
+            flat = z_e.reshape(-1, D_)
+            emb = self.sd["quantizer.embedding"]
+            ws = c["soft_vq_tau_warm_steps"]
+            t = 1.0 if ws <= 0 else min(1.0, max(0.0, self.training_steps) / float(ws))
+            tau = c["soft_vq_tau_end"] if ws <= 0 else (1.0 - t) * c["soft_vq_tau_start"] + t * c["soft_vq_tau_end"]
+            d2 = ((flat[:, None, :] - emb[None]) ** 2).sum(-1)
+            probs = torch.softmax(-d2 / max(1e-8, tau), dim=-1)
+            z_soft = (probs @ emb).view(B_, N_, D_)
+            with torch.no_grad():
+                idx_f = torch.argmin(d2, dim=1)
+                z_q = emb[idx_f].view(B_, N_, D_)
+            aw = c["soft_vq_alpha_warm_steps"]
+            alpha = 1.0 if aw <= 0 else min(1.0, float(self.training_steps) / float(aw))
+            z_dec = z_e + ((1 - alpha) * z_soft + alpha * z_q - z_e).detach()
+            if upd:
+                self._ema_update(flat.detach(), idx_f)
+            _, ppl, dead = self._usage_stats(idx_f)
+            idx = idx_f.view(B_, N_)
         else:
             upd = self.training and (self.training_steps >= c["ema_update_freeze_steps"])
             z_dec, z_q, idx, st = self.quantize(z_e, do_ema_update=upd)

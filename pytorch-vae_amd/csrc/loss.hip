@@ -21,7 +21,7 @@ enum { T_VALID = 0, T_PAIR = 1, T_TRI = 2, T_QUAD = 3, T_FIVE = 4, T_ANY3 = 5, T
 // ---- per-sample partial sums ---------------------------------------------------------------
 enum {
     P_RAW = 0, P_ALN, P_BEST, P_RMSD_RAW, P_RMSD_BEST, P_CE, P_ACC, P_SSTV, P_BL, P_BA, P_DIR, P_DIH, P_TV2, P_TAU,
-    P_PDM, P_LRPDM, P_WINK, P_COMMIT, P_COUNT
+    P_PDM, P_LRPDM, P_WINK, P_COMMIT, P_KAPPA, P_COUNT
 };
 
 // ---- output metric slots (order of the reference's result dict) ------------------------------
@@ -39,6 +39,8 @@ struct LossCfg {
     int pdm_window, wk_size, wk_stride, lr_sep, lr_stride, lr_max;
     int n_lr_pairs, n_windows;  // enumerated on the host exactly like the reference's python loops
     int t_wk;                   // offset of the per-window selected-sample counts in the table
+    int has_stats;              // set_data_stats(): geometry terms see x*sd + mu (reference to_real, :1218-1227)
+    float sd[3], mu[3];
 };
 
 struct V3 { float x, y, z; };
@@ -321,6 +323,12 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
     int* lab = reinterpret_cast<int*>(dhg + 2 * L);   // [L]
     float* red = reinterpret_cast<float*>(lab + L);   // [4]
     float* Rt = red + 4;          // [13] R(9) t(3) ok
+    float* rrb = Rt + 16;         // [3L] real-space recon   } only distinct from rx/gx/g when data stats are set
+    float* grb = rrb + 3 * L;     // [3L] real-space target  }
+    float* gRb = grb + 3 * L;     // [3L] d loss / d real-space recon
+    const float* rr = c.has_stats ? rrb : rx;
+    const float* gr = c.has_stats ? grb : gx;
+    float* gR = c.has_stats ? gRb : g;
 
     const float* rb = recons + (size_t)b * L * 6;
     const float* tb = target + (size_t)b * L * 6;
@@ -330,6 +338,11 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
             gx[3 * l + k] = tb[6 * l + k];
             lg[3 * l + k] = rb[6 * l + 3 + k];
             g[3 * l + k] = 0.f;
+            if (c.has_stats) {
+                rrb[3 * l + k] = rb[6 * l + k] * c.sd[k] + c.mu[k];
+                grb[3 * l + k] = tb[6 * l + k] * c.sd[k] + c.mu[k];
+                gRb[3 * l + k] = 0.f;
+            }
         }
         mk[l] = mask ? (float)mask[(size_t)b * L + l] : 1.f;
         // label = argmax of the one-hot target (first maximum)
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
         V3 ga = v3(0, 0, 0);
         if (on) {
             const float pm = mk[l] * mk[l + 1];
-            const V3 vr = ld3(rx, l + 1) - ld3(rx, l), vg = ld3(gx, l + 1) - ld3(gx, l);
+            const V3 vr = ld3(rr, l + 1) - ld3(rr, l), vg = ld3(gr, l + 1) - ld3(gr, l);
             const float e = norm(vr) - norm(vg);
             bl += pm * e * e;
             const V3 ur = unit(vr), ug = unit(vg);
@@ -476,44 +489,49 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
             ga = (2.f * c.bl_w * inv_pair * pm * e) * norm_grad(vr);
             if (c.dir_w != 0.f) ga = ga + unit_bwd(vr, (-c.dir_w * inv_pair * pm) * ug);
         }
-        if (on) add3(g, l + 1, ga);
+        if (on) add3(gR, l + 1, ga);
         __syncthreads();
-        if (on) add3(g, l, v3(-ga.x, -ga.y, -ga.z));
+        if (on) add3(gR, l, v3(-ga.x, -ga.y, -ga.z));
         __syncthreads();
     }
     bl = block_sum(bl, red); dr = block_sum(dr, red);
 
     // ---------------- triple terms: bond angle (:1244), xyz TV2 (:1312) / Frenet kappa (:1044-1052) ----------------
-    float ba = 0.f, tv2 = 0.f;
+    float ba = 0.f, tv2 = 0.f, kap = 0.f;
     FOR_POS(L - 2) {
         const int l = base_ + tid;
         const bool on = l < L - 2;
-        V3 g0 = v3(0, 0, 0), g1 = g0, g2 = g0;
+        V3 g0 = v3(0, 0, 0), g1 = g0, g2 = g0, t0 = g0, t1 = g0, t2 = g0;
         if (on) {
             const float tm = mk[l] * mk[l + 1] * mk[l + 2];
-            const V3 p0 = ld3(rx, l), p1 = ld3(rx, l + 1), p2 = ld3(rx, l + 2);
+            const V3 p0 = ld3(rr, l), p1 = ld3(rr, l + 1), p2 = ld3(rr, l + 2);
             const V3 v1 = p1 - p0, v2 = p2 - p1;
             const V3 u1 = unit(v1), u2 = unit(v2);
-            const V3 q0 = ld3(gx, l), q1 = ld3(gx, l + 1), q2 = ld3(gx, l + 2);
+            const V3 q0 = ld3(gr, l), q1 = ld3(gr, l + 1), q2 = ld3(gr, l + 2);
             const float cg = dot(unit(q1 - q0), unit(q2 - q1));
             const float e = dot(u1, u2) - cg;
             ba += tm * e * e;
             const float dc = 2.f * c.ba_w * inv_tri * tm * e;
             const V3 dv1 = unit_bwd(v1, dc * u2), dv2 = unit_bwd(v2, dc * u1);
-            const V3 d2 = v2 - v1;
-            tv2 += tm * dot(d2, d2);
-            const float wt = 2.f * (c.tv_l + c.kap_w) * inv_tri * tm;
-            g0 = v3(-dv1.x, -dv1.y, -dv1.z) + wt * d2;
-            g1 = (dv1 - dv2) - (2.f * wt) * d2;
-            g2 = dv2 + wt * d2;
+            const V3 d2r = v2 - v1;                                   // Frenet kappa lives in real space
+            kap += tm * dot(d2r, d2r);
+            const float wk = 2.f * c.kap_w * inv_tri * tm;
+            g0 = v3(-dv1.x, -dv1.y, -dv1.z) + wk * d2r;
+            g1 = (dv1 - dv2) - (2.f * wk) * d2r;
+            g2 = dv2 + wk * d2r;
+            const V3 d2n = (ld3(rx, l + 2) - ld3(rx, l + 1)) - (ld3(rx, l + 1) - ld3(rx, l));   // xyz TV2: normalised space
+            tv2 += tm * dot(d2n, d2n);
+            const float wt = 2.f * c.tv_l * inv_tri * tm;
+            t0 = wt * d2n; t1 = (-2.f * wt) * d2n; t2 = wt * d2n;
         }
-        if (on) add3(g, l, g0);
+        if (on) { add3(gR, l, g0); add3(g, l, t0); }
         __syncthreads();
-        if (on) add3(g, l + 1, g1);
+        if (on) { add3(gR, l + 1, g1); add3(g, l + 1, t1); }
         __syncthreads();
-        if (on) add3(g, l + 2, g2);
+        if (on) { add3(gR, l + 2, g2); add3(g, l + 2, t2); }
         __syncthreads();
     }
+    kap = block_sum(kap, red);
     ba = block_sum(ba, red); tv2 = block_sum(tv2, red);
 
     // ---------------- dihedral (:1278) and Frenet tau (:1056-1065) ----------------
@@ -522,9 +540,9 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
     if (nd > 0) {
         for (int i = tid; i < nd; i += 256) {
             float co, si;
-            dihedral_fwd(ld3(rx, i), ld3(rx, i + 1), ld3(rx, i + 2), ld3(rx, i + 3), co, si);
+            dihedral_fwd(ld3(rr, i), ld3(rr, i + 1), ld3(rr, i + 2), ld3(rr, i + 3), co, si);
             dhr[2 * i] = co; dhr[2 * i + 1] = si;
-            dihedral_fwd(ld3(gx, i), ld3(gx, i + 1), ld3(gx, i + 2), ld3(gx, i + 3), co, si);
+            dihedral_fwd(ld3(gr, i), ld3(gr, i + 1), ld3(gr, i + 2), ld3(gr, i + 3), co, si);
             dhg[2 * i] = co; dhg[2 * i + 1] = si;
         }
         __syncthreads();
@@ -554,14 +572,14 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
                 const int i = base_ + tid;
                 const bool on = i < nd;
                 V3 g0 = v3(0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
-                if (on) dihedral_bwd(ld3(rx, i), ld3(rx, i + 1), ld3(rx, i + 2), ld3(rx, i + 3), dcs[2 * i], dcs[2 * i + 1], g0, g1, g2, g3);
-                if (on) add3(g, i, g0);
+                if (on) dihedral_bwd(ld3(rr, i), ld3(rr, i + 1), ld3(rr, i + 2), ld3(rr, i + 3), dcs[2 * i], dcs[2 * i + 1], g0, g1, g2, g3);
+                if (on) add3(gR, i, g0);
                 __syncthreads();
-                if (on) add3(g, i + 1, g1);
+                if (on) add3(gR, i + 1, g1);
                 __syncthreads();
-                if (on) add3(g, i + 2, g2);
+                if (on) add3(gR, i + 2, g2);
                 __syncthreads();
-                if (on) add3(g, i + 3, g3);
+                if (on) add3(gR, i + 3, g3);
                 __syncthreads();
             }
         }
@@ -582,14 +600,14 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
                 V3 ga = v3(0, 0, 0);
                 if (on) {
                     const float pm = mk[i] * mk[i + d];
-                    const V3 va = ld3(rx, i) - ld3(rx, i + d), vb = ld3(gx, i) - ld3(gx, i + d);
+                    const V3 va = ld3(rr, i) - ld3(rr, i + d), vb = ld3(gr, i) - ld3(gr, i + d);
                     const float e = norm(va) - norm(vb);
                     s += pm * e * e;
                     ga = (2.f * c.pdm_w * wn * iden * pm * e) * norm_grad(va);
                 }
-                if (on) add3(g, i, ga);
+                if (on) add3(gR, i, ga);
                 __syncthreads();
-                if (on) add3(g, i + d, v3(-ga.x, -ga.y, -ga.z));
+                if (on) add3(gR, i + d, v3(-ga.x, -ga.y, -ga.z));
                 __syncthreads();
             }
             pdm += wn * iden * block_sum(s, red);
@@ -616,14 +634,14 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
                     i = k * st; j = i + sep;
                     const float pm = mk[i] * mk[j];
                     const float iden = tden(T_LR + p0 + k);
-                    const V3 va = ld3(rx, j) - ld3(rx, i), vb = ld3(gx, j) - ld3(gx, i);
+                    const V3 va = ld3(rr, j) - ld3(rr, i), vb = ld3(gr, j) - ld3(gr, i);
                     const float e = norm(va) - norm(vb);
                     s += iden * pm * e * e;
                     ga = (2.f * c.lr_w * wn * iden * pm * e) * norm_grad(va);
                 }
-                if (on) add3(g, j, ga);
+                if (on) add3(gR, j, ga);
                 __syncthreads();
-                if (on) add3(g, i, v3(-ga.x, -ga.y, -ga.z));
+                if (on) add3(gR, i, v3(-ga.x, -ga.y, -ga.z));
                 __syncthreads();
             }
             lrp += wn * block_sum(s, red);
@@ -647,21 +665,21 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
                 cntv = block_sum(cntv, red);
                 const bool selected = !c.masked || cntv >= 3.f;
                 if (!selected) continue;          // uniform across the block
-                const bool ok = block_kabsch(rx, gx, mk, s0, c.wk_size, dred, Rt);
+                const bool ok = block_kabsch(rr, gr, mk, s0, c.wk_size, dred, Rt);
                 if (!ok) continue;
                 const float den = c.masked ? fmaxf(cntv, 1.f) : (float)(c.wk_size * 3);
                 const float coef = c.wk_w * wn / ((float)nsel * den);
                 float s = 0.f;
                 for (int l = tid; l < c.wk_size; l += 256) {
                     const int p = s0 + l;
-                    const V3 x = ld3(rx, p);
+                    const V3 x = ld3(rr, p);
                     const V3 y = v3(x.x * Rt[0] + x.y * Rt[3] + x.z * Rt[6] + Rt[9], x.x * Rt[1] + x.y * Rt[4] + x.z * Rt[7] + Rt[10],
                                     x.x * Rt[2] + x.y * Rt[5] + x.z * Rt[8] + Rt[11]);
-                    const V3 d = y - ld3(gx, p);
+                    const V3 d = y - ld3(gr, p);
                     s += mk[p] * dot(d, d);
                     const V3 dx = v3(d.x * Rt[0] + d.y * Rt[1] + d.z * Rt[2], d.x * Rt[3] + d.y * Rt[4] + d.z * Rt[5],
                                      d.x * Rt[6] + d.y * Rt[7] + d.z * Rt[8]);
-                    add3(g, p, (2.f * coef * mk[p]) * dx);
+                    add3(gR, p, (2.f * coef * mk[p]) * dx);
                 }
                 wink += wn / ((float)nsel * den) * block_sum(s, red);
             }
@@ -688,13 +706,13 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
     // ---------------- outputs ----------------
     float* dxb = d_recons + (size_t)b * L * 6;
     for (int l = tid; l < L; l += 256)
-        for (int k = 0; k < 3; ++k) dxb[6 * l + k] = g[3 * l + k];
+        for (int k = 0; k < 3; ++k) dxb[6 * l + k] = c.has_stats ? g[3 * l + k] + gRb[3 * l + k] * c.sd[k] : g[3 * l + k];
     if (tid == 0) {
         float* p = part + (size_t)b * P_COUNT;
         p[P_RAW] = raw; p[P_ALN] = aln; p[P_BEST] = best;
         p[P_RMSD_RAW] = sqrtf(fmaxf(raw, 1e-12f)); p[P_RMSD_BEST] = sqrtf(fmaxf(best, 1e-12f));
         p[P_CE] = ce; p[P_ACC] = acc; p[P_SSTV] = sstv; p[P_BL] = bl; p[P_BA] = ba; p[P_DIR] = dr; p[P_DIH] = dih;
-        p[P_TV2] = tv2; p[P_TAU] = tau; p[P_PDM] = pdm; p[P_LRPDM] = lrp; p[P_WINK] = wink; p[P_COMMIT] = commit;
+        p[P_TV2] = tv2; p[P_TAU] = tau; p[P_KAPPA] = kap; p[P_PDM] = pdm; p[P_LRPDM] = lrp; p[P_WINK] = wink; p[P_COMMIT] = commit;
     }
 }
 
@@ -721,9 +739,8 @@ __global__ void loss_finish_kernel(const float* __restrict__ part, const int* __
     double dih = 0.0;
     if (c.L >= 4) dih = c.masked ? acc[P_DIH] / cnt(T_QUAD) : acc[P_DIH] / (2.0 * B * (c.L - 3));
     const double geom = c.bl_w * bl + c.ba_w * ba + c.dir_w * dr + c.dih_w * dih;
-    const double tri = c.L >= 3 ? acc[P_TV2] / cnt(T_TRI) : 0.0;
-    const double xyz_tv = (c.tv_l > 0.f) ? tri : 0.0;
-    const double kappa = (c.kap_w > 0.f) ? tri : 0.0;
+    const double xyz_tv = (c.tv_l > 0.f && c.L >= 3) ? acc[P_TV2] / cnt(T_TRI) : 0.0;
+    const double kappa = (c.kap_w > 0.f && c.L >= 3) ? acc[P_KAPPA] / cnt(T_TRI) : 0.0;
     const double tau = (c.tau_w > 0.f && c.L >= 5) ? acc[P_TAU] / cnt(T_FIVE) : 0.0;
     const double vq = c.use_vq ? c.beta * acc[P_COMMIT] / (B * c.Ntok * c.D) : 0.0;
     const double pdm = acc[P_PDM], lrp = acc[P_LRPDM], wink = acc[P_WINK];
@@ -753,12 +770,14 @@ __global__ void loss_finish_kernel(const float* __restrict__ part, const int* __
 
 // weights: 16 floats {rmsd_w, ss_w, bl_w, ba_w, dir_w, dih_w, xyz_tv_lambda, pdm_w, win_kabsch_w, kappa_w, tau_w,
 //                     lr_pdm_w, xyz_align_alpha, ss_tv_lambda, label_smoothing, beta}
+// data_stats (HOST, may be NULL): {std_x, std_y, std_z, mean_x, mean_y, mean_z} of set_data_stats()
 // iparams: 6 ints {pdm_window, win_kabsch_size, win_kabsch_stride, lr_min_sep, lr_stride, lr_max_offsets}
 // metrics: 24 floats (order = reference dict + the 5 optional keys);  workspace: ints table + per-sample partials.
 extern "C" int vqh_loss_fwd_bwd(const float* recons, const float* target, const unsigned char* mask, int masked,
                                 const float* ze, const float* zq, const float* vq_stats, int B, int L, int Ntok, int D,
-                                int use_vq, const float* weights, const int* iparams, float* d_recons, float* d_ze,
-                                float* metrics, float* workspace, long long workspace_floats, hipStream_t stream) {
+                                int use_vq, const float* weights, const int* iparams, const float* data_stats,
+                                float* d_recons, float* d_ze, float* metrics, float* workspace,
+                                long long workspace_floats, hipStream_t stream) {
     VQH_CHECK_ARG(B > 0 && L > 0, "vqh_loss_fwd_bwd: bad shape");
     VQH_CHECK_ARG(recons && target && weights && iparams && d_recons && metrics && workspace, "vqh_loss_fwd_bwd: null pointer");
     VQH_CHECK_ARG(!use_vq || (ze && zq && d_ze), "vqh_loss_fwd_bwd: VQ tensors missing");
@@ -770,6 +789,8 @@ extern "C" int vqh_loss_fwd_bwd(const float* recons, const float* target, const 
     c.label_smoothing = weights[14]; c.beta = weights[15];
     c.pdm_window = iparams[0]; c.wk_size = iparams[1]; c.wk_stride = iparams[2]; c.lr_sep = iparams[3];
     c.lr_stride = iparams[4]; c.lr_max = iparams[5];
+    c.has_stats = data_stats ? 1 : 0;
+    for (int k = 0; k < 3; ++k) { c.sd[k] = data_stats ? data_stats[k] : 1.f; c.mu[k] = data_stats ? data_stats[3 + k] : 0.f; }
     VQH_CHECK_ARG(c.pdm_window <= 33, "vqh_loss_fwd_bwd: pdm_window > 33 unsupported");
     // enumerate long-range pairs and windows exactly like the reference loops
     int npairs = 0;
@@ -796,7 +817,7 @@ extern "C" int vqh_loss_fwd_bwd(const float* recons, const float* target, const 
     hipError_t e = hipMemsetAsync(table, 0, sizeof(int) * table_ints, stream);
     if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
     hipLaunchKernelGGL(loss_counts_kernel, dim3(B), dim3(256), (size_t)L, stream, mask, c, table);
-    const size_t smem = sizeof(float) * (size_t)(8 + 23 * L + 4 + 16 + 4);
+    const size_t smem = sizeof(float) * (size_t)(8 + 23 * L + 4 + 16 + 9 * L + 4);
     VQH_CHECK_ARG(smem <= 160 * 1024, "vqh_loss_fwd_bwd: sequence too long for the LDS-resident loss kernel");
     static bool attr_set = false;
     if (!attr_set) {

@@ -374,6 +374,100 @@ __global__ void embed_scatter_kernel(const float* __restrict__ s, float* __restr
     db[h] = (beta != 0.f) ? beta * db[h] + v : v;
 }
 
+// rigid augmentation + coordinate noise of the INPUT only (reference models/vq_vae.py:775-792, _random_rotation :331-345)
+// u[b,0:3] uniforms -> unit quaternion -> R_b ; out.xyz = R_b . xyz + t_b (+ noise) ; the SS channels are copied.
+__global__ void augment_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ t,
+                               const float* __restrict__ noise, float* __restrict__ out, int B, int L) {
+    const long long total = (long long)B * L;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(e / L);
+        const float* xi = x + e * 6;
+        float px = xi[0], py = xi[1], pz = xi[2];
+        if (u) {
+            const float u1 = u[b * 3], u2 = u[b * 3 + 1], u3 = u[b * 3 + 2];
+            const float two_pi = 6.28318530717958647692f;
+            const float qx = sqrtf(1.f - u1) * sinf(two_pi * u2), qy = sqrtf(1.f - u1) * cosf(two_pi * u2);
+            const float qz = sqrtf(u1) * sinf(two_pi * u3), qw = sqrtf(u1) * cosf(two_pi * u3);
+            const float r00 = 1.f - 2.f * (qy * qy + qz * qz), r01 = 2.f * (qx * qy - qz * qw), r02 = 2.f * (qx * qz + qy * qw);
+            const float r10 = 2.f * (qx * qy + qz * qw), r11 = 1.f - 2.f * (qx * qx + qz * qz), r12 = 2.f * (qy * qz - qx * qw);
+            const float r20 = 2.f * (qx * qz - qy * qw), r21 = 2.f * (qy * qz + qx * qw), r22 = 1.f - 2.f * (qx * qx + qy * qy);
+            const float ax = r00 * px + r01 * py + r02 * pz + t[b * 3];
+            const float ay = r10 * px + r11 * py + r12 * pz + t[b * 3 + 1];
+            const float az = r20 * px + r21 * py + r22 * pz + t[b * 3 + 2];
+            px = ax; py = ay; pz = az;
+        }
+        if (noise) { px += noise[e * 3]; py += noise[e * 3 + 1]; pz += noise[e * 3 + 2]; }
+        float* o = out + e * 6;
+        o[0] = px; o[1] = py; o[2] = pz; o[3] = xi[3]; o[4] = xi[4]; o[5] = xi[5];
+    }
+}
+
+// P[r,:] = softmax(scale * S[r,:] + colbias) in place; one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, int ld, const float* __restrict__ colbias,
+                                                           float scale, int R, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float* sr = S + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, scale * sr[k] + (colbias ? colbias[k] : 0.f));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float e = expf(scale * sr[k] + (colbias ? colbias[k] : 0.f) - mx);
+        sr[k] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int k = lane; k < K; k += 64) sr[k] *= inv;
+}
+
+// dlogits = P * (g - sum_k P_k g_k) in place (g is a per-column vector)
+__global__ __launch_bounds__(256) void softmax_bwd_colgrad_kernel(float* __restrict__ P, int ld, const float* __restrict__ g,
+                                                                  int R, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float* pr = P + (size_t)row * ld;
+    float dotv = 0.f;
+    for (int k = lane; k < K; k += 64) dotv += pr[k] * g[k];
+    dotv = wave_sum(dotv);
+    for (int k = lane; k < K; k += 64) pr[k] = pr[k] * (g[k] - dotv);
+}
+
+// usage-entropy regulariser (reference :1299-1309): pc = colsum/R ; reg = lambda * sum pc*log(max(pc,1e-12));
+// g[k] = d reg / d P[r,k] = lambda/R * d(pc log clamp(pc))/dpc ; metrics[loss] += reg ; metrics[usage_reg] = reg
+__global__ __launch_bounds__(256) void usage_entropy_finish_kernel(const float* __restrict__ colsum, int K, float invR,
+                                                                   float lambda, float* __restrict__ g,
+                                                                   float* __restrict__ metrics, int i_loss, int i_reg) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float pc = colsum[k] * invR;
+        const float lg = logf(fmaxf(pc, 1e-12f));
+        acc += pc * lg;
+        g[k] = lambda * invR * (lg + (pc > 1e-12f ? 1.f : 0.f));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float reg = lambda * (red[0] + red[1] + red[2] + red[3]);
+        metrics[i_loss] += reg;
+        metrics[i_reg] = reg;
+    }
+}
+
+// soft-VQ mix (reference :843-853): z_dec = ze + (((1-alpha)*z_soft + alpha*z_hard) - ze)
+__global__ void vq_mix_kernel(const float* __restrict__ ze, const float* __restrict__ zsoft, const float* __restrict__ zhard,
+                              float alpha, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float mix = __fadd_rn(__fmul_rn(1.f - alpha, zsoft[i]), __fmul_rn(alpha, zhard[i]));
+        out[i] = __fadd_rn(ze[i], __fsub_rn(mix, ze[i]));
+    }
+}
+
 inline int blocks_for(long long n, int per_block = 256, int cap = 4096) {
     long long b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -557,5 +651,48 @@ extern "C" int vqh_memset(void* ptr, int value, long long bytes, hipStream_t str
     if (bytes == 0) return VQH_OK;
     hipError_t e = hipMemsetAsync(ptr, value, (size_t)bytes, stream);
     if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+    return VQH_OK;
+}
+
+extern "C" int vqh_augment(const float* x, const float* u, const float* t, const float* noise, float* out, int B, int L,
+                           hipStream_t stream) {
+    VQH_CHECK_ARG(B >= 0 && L >= 0 && x && out && (!u || t), "vqh_augment: bad argument");
+    if (B == 0 || L == 0) return VQH_OK;
+    hipLaunchKernelGGL(augment_kernel, dim3(blocks_for((long long)B * L)), dim3(256), 0, stream, x, u, t, noise, out, B, L);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_softmax_rows(float* S, int ld, const float* colbias, float scale, int R, int K, hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0 && K > 0 && ld >= K && S, "vqh_softmax_rows: bad argument");
+    if (R == 0) return VQH_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, S, ld, colbias, scale, R, K);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_softmax_bwd_colgrad(float* P, int ld, const float* g, int R, int K, hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0 && K > 0 && ld >= K && P && g, "vqh_softmax_bwd_colgrad: bad argument");
+    if (R == 0) return VQH_OK;
+    hipLaunchKernelGGL(softmax_bwd_colgrad_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, P, ld, g, R, K);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_usage_entropy_finish(const float* colsum, int K, int R, float lambda, float* g, float* metrics,
+                                        int i_loss, int i_reg, hipStream_t stream) {
+    VQH_CHECK_ARG(K > 0 && R > 0 && colsum && g && metrics, "vqh_usage_entropy_finish: bad argument");
+    hipLaunchKernelGGL(usage_entropy_finish_kernel, dim3(1), dim3(256), 0, stream, colsum, K, 1.f / (float)R, lambda, g,
+                       metrics, i_loss, i_reg);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+extern "C" int vqh_vq_mix(const float* ze, const float* zsoft, const float* zhard, float alpha, float* out, long long n,
+                          hipStream_t stream) {
+    VQH_CHECK_ARG(n >= 0 && ze && zsoft && zhard && out, "vqh_vq_mix: bad argument");
+    if (n == 0) return VQH_OK;
+    hipLaunchKernelGGL(vq_mix_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, ze, zsoft, zhard, alpha, out, n);
+    VQH_LAUNCH_CHECK();
     return VQH_OK;
 }

@@ -16,7 +16,8 @@ namespace {
 
 __device__ __forceinline__ int kmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__global__ void row_sqnorm_kernel(const float* __restrict__ X, int ld, int rows, int D, float* __restrict__ out) {
+__global__ void row_sqnorm_kernel(const float* __restrict__ X, int ld, int rows, int D, float* __restrict__ out,
+                                  float scale = 1.f) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -26,7 +27,7 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ X, int ld, int rows,
         s += v * v;
     }
     s = wave_sum(s);
-    if (lane == 0) out[row] = s;
+    if (lane == 0) out[row] = s * scale;
 }
 
 // one wave per 32 rows; codes in tiles of 32; D multiple of 8.
@@ -348,8 +349,8 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     float* enorm = workspace;
     float* znorm = workspace + K;
     unsigned char* amb = reinterpret_cast<unsigned char*>(workspace + K + R);
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, enorm);
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, R, D, znorm);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, enorm, 1.f);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, R, D, znorm, 1.f);
     hipLaunchKernelGGL(vq_nearest_kernel, dim3((R + 31) / 32), dim3(64), 0, stream, Z, ldz, E, lde, enorm, znorm, idx_out,
                        idx_offset, amb, R, K, D, rel_tol);
     hipLaunchKernelGGL(vq_refine_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, E, lde, idx_out, idx_offset, amb,
@@ -444,6 +445,15 @@ extern "C" int vqh_vq_reinit(const float* usage, float threshold, const long lon
     VQH_CHECK_ARG(K > 0 && D > 0 && usage && pick && rows && emb && ema_emb && ema_cnt, "vqh_vq_reinit: bad argument");
     hipLaunchKernelGGL(vq_reinit_kernel, dim3(K), dim3(64), 0, stream, usage, threshold, pick, rows, ldr, emb, ema_emb,
                        ema_cnt, K, D);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+// out[r] = scale * ||X[r,:]||^2   (soft-VQ logits need -||e_k||^2 / tau as a column bias, reference :838-840)
+extern "C" int vqh_row_sqnorm(const float* X, int ld, int rows, int D, float* out, float scale, hipStream_t stream) {
+    VQH_CHECK_ARG(rows >= 0 && D > 0 && ld >= D && X && out, "vqh_row_sqnorm: bad argument");
+    if (rows == 0) return VQH_OK;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, X, ld, rows, D, out, scale);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }

@@ -226,13 +226,6 @@ class VQVAE(nn.Module):
         self._data_mean = self._data_std = None
         if H % self.num_heads or (H // self.num_heads) not in (16, 32, 64):
             raise ValueError("hidden_dim / num_heads must be 16, 32 or 64 for the HIP attention kernels")
-        if self.soft_vq_use:
-            raise NotImplementedError("soft-VQ branch (reference :828-861) is disabled in both shipped configs and "
-                                      "not on the HIP path yet")
-        if self.rigid_aug_prob > 0.0 or self.max_noise_std > 0.0:
-            raise NotImplementedError("rigid augmentation / coordinate noise (reference :775-792) are off in both "
-                                      "shipped configs and not on the HIP path yet")
-
         # ---- parameters, created in the reference's order (same seed -> same initial weights) ----
         self.input_proj = nn.Linear(3, H)
         self.ss_input_proj = nn.Linear(3, H)

@@ -419,6 +419,25 @@ class StepEngine:
         call("vqh_colsum", dres, N * H, B, N * H, self.G["tokenizer.queries"], 0.0, self.ws, self.ws.numel())
         return d_hf
 
+    def _soft_vq_params(self):
+        """(tau, alpha) of the soft-VQ branch (:835-836, :849) or None when the hard path is taken."""
+        m = self.m
+        if not (m.use_vq and m.soft_vq_use and self.train and m.num_quantizers == 1):
+            return None
+        ws = m.soft_vq_tau_warm_steps
+        if ws <= 0:
+            tau = m.soft_vq_tau_end
+        else:
+            t = min(1.0, max(0.0, m.training_steps) / float(ws))
+            tau = (1.0 - t) * m.soft_vq_tau_start + t * m.soft_vq_tau_end
+        aw = m.soft_vq_alpha_warm_steps
+        alpha = 1.0 if aw <= 0 else min(1.0, float(m.training_steps) / float(aw))
+        return float(tau), float(alpha)
+
+    def _soft_vq_key(self):
+        p = self._soft_vq_params() if self.m.use_vq else None
+        return p
+
     def quantize(self, z_e, B, do_ema_update):
         """VectorQuantizerEMA.forward (models/vq_vae.py:170-283). z_e [B*N, D] -> z_st, z_q, idx, stats"""
         q = self.m.quantizer
@@ -430,7 +449,8 @@ class StepEngine:
         cnt = self.flat_gx[self.n_flat:self.n_flat + K]
         ssum = self.flat_gx[self.n_flat + K:self.n_flat + K + K * D].view(K, D)
         usage = self.T("vq.usage", K)
-        defer = bool(self.defer_ema and Q == 1)
+        soft_on = self._soft_vq_params() is not None
+        defer = bool((self.defer_ema and Q == 1) or soft_on)      # soft-VQ probabilities use the pre-refresh table
         upd = bool(self.train and do_ema_update)
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size() > 1
@@ -460,6 +480,23 @@ class StepEngine:
             rows = nxt
         z_q, z_st = self.T("vq.z_q", R, D), self.T("vq.z_st", R, D)
         call("vqh_vq_finish", zq_lv, Q, z_e, D, z_q, z_st, R, D)
+        soft = self._soft_vq_params()
+        if soft is not None:
+            # soft-VQ (:828-861): decoder input = z_e + ((1-a) softmax(-d2/tau).E + a z_hard - z_e), value only
+            tau, alpha = soft
+            tau = max(1e-8, tau)
+            S = self.T("vq.soft", R, K)
+            L.gemm(1, 1, R, K, D, z_e, D, emb, D, S, K)
+            cb = self.T("vq.soft_bias", K)
+            call("vqh_row_sqnorm", emb, D, K, D, cb, -1.0 / tau)
+            call("vqh_softmax_rows", S, K, cb, 2.0 / tau, R, K)         # -(|z|^2 - 2 z.e + |e|^2)/tau up to a row constant
+            zs = self.T("vq.z_soft", R, D)
+            L.gemm(1, 0, R, D, K, S, K, emb, D, zs, D)
+            call("vqh_vq_mix", z_e, zs, z_q, alpha, z_st, R * D)
+            call("vqh_vq_usage_stats", usage, K, float(Q * R), None, None, self.vq_stats)   # _compute_stats: no epoch sums
+            if not self.defer_ema:
+                self.finish_ema()
+            return z_st, z_q, idx, self.vq_stats
         call("vqh_vq_usage_stats", usage, K, float(Q * R), q._ep_usage, q._ep_cnt, self.vq_stats)
         return z_st, z_q, idx, self.vq_stats
 
@@ -569,11 +606,37 @@ class StepEngine:
     def forward(self, x, mask, train=True):
         """VQVAE.forward (models/vq_vae.py:767-901) without aug/noise/soft-VQ (see DESIGN.md scope)."""
         self.train = bool(train)
+        self.defer_ema = False
+        x_in = self.augment_input(x)
         upd = self._host_prologue()
-        out = self._forward_core(x, mask, upd)
+        out = self._forward_core(x_in, mask, upd)
         self.finish_ema()
         if upd:
             self.maybe_reinit_dead_codes()
+        return out
+
+    def augment_input(self, x):
+        """Input-only rigid augmentation and coordinate noise (:775-792). Random draws come from torch's generators
+        like the reference (host gate torch.rand(()), device torch.rand / randn), the transform runs in vqh_augment."""
+        m = self.m
+        if not self.train:
+            return x
+        rot = m.rigid_aug_prob > 0.0 and float(torch.rand(())) < m.rigid_aug_prob
+        std = 0.0
+        if m.max_noise_std > 0.0:
+            f = min(1.0, m.training_steps / float(m.noise_warmup_steps)) if m.noise_warmup_steps > 0 else 1.0
+            std = m.max_noise_std * f
+        if not rot and std <= 0.0:
+            return x
+        B, Lq = x.shape[0], x.shape[1]
+        u = t = noise = None
+        if rot:
+            u = torch.stack([torch.rand(B, device=self.dev) for _ in range(3)], dim=1).contiguous()
+            t = (torch.randn(B, 1, 3, device=self.dev) * 0.02).reshape(B, 3).contiguous()
+        if std > 0.0:
+            noise = (torch.randn(B, Lq, 3, device=self.dev) * std).contiguous()
+        out = self.T("in.x_aug", B, Lq, 6)
+        call("vqh_augment", x, u, t, noise, out, B, Lq)
         return out
 
     def _host_prologue(self):
@@ -611,10 +674,10 @@ class StepEngine:
         """VQVAE.loss_function (models/vq_vae.py:1097-1388): metrics (device vector) + d_rec, d_ze."""
         m = self.m
         B, Lq = target.shape[0], target.shape[1]
-        if m.usage_entropy_lambda > 0.0:
-            raise NotImplementedError("usage_entropy_lambda > 0 is not on the HIP path yet (0 in both shipped configs)")
-        if m._data_std is not None:
-            raise NotImplementedError("set_data_stats() rescaling is not on the HIP path (never called by the harness)")
+        stats6 = None
+        if m._data_std is not None:                                   # set_data_stats(): to_real() of :1218-1227
+            mean = m._data_mean if m._data_mean is not None else torch.zeros(3)
+            stats6 = [float(v) for v in m._data_std.reshape(-1).tolist()] + [float(v) for v in mean.reshape(-1).tolist()]
         g = lambda k, d: float(weights.get(k, d))
         w = [g("rmsd_weight", 1.0), g("ss_weight", 1.0), g("bond_length_weight", 0.0), g("bond_angle_weight", 0.0),
              g("dir_weight", 0.0), g("dih_weight", 0.0), g("xyz_tv_lambda", 0.0), g("pdm_weight", 0.0),
@@ -627,14 +690,30 @@ class StepEngine:
         import ctypes as C
         wa = (C.c_float * 16)(*w)
         ia = (C.c_int * 6)(*ip)
+        sa = (C.c_float * 6)(*stats6) if stats6 is not None else None
         d_rec = self.T("loss.d_rec", B * Lq, 6)
         use_vq = bool(m.use_vq)
         Ntok = z_e.shape[0] // B
         d_ze = self.T("loss.d_ze", z_e.shape[0], self.D)
         call("vqh_loss_fwd_bwd", rec, target, mask, 1 if mask is not None else 0, z_e if use_vq else None,
              z_q if use_vq else None, stats if use_vq else None, B, Lq, Ntok, self.D, int(use_vq),
-             C.cast(wa, C.c_void_p).value, C.cast(ia, C.c_void_p).value, d_rec, d_ze if use_vq else None, self.metrics,
+             C.cast(wa, C.c_void_p).value, C.cast(ia, C.c_void_p).value,
+             C.cast(sa, C.c_void_p).value if sa is not None else None, d_rec, d_ze if use_vq else None, self.metrics,
              self.ws, self.ws.numel())
+        lam = float(m.usage_entropy_lambda)
+        if lam > 0.0 and use_vq and z_e.shape[0] > 0:
+            # usage-entropy regulariser (:1299-1309): softmax(z_e . E^T) -> mean code probability -> -lambda * entropy,
+            # with its gradient added onto d_ze; uses the table as it stands after this step's EMA refresh
+            q = m.quantizer
+            R, K = z_e.shape[0], q.K
+            logits = self.T("ue.logits", R, K)
+            L.gemm(1, 1, R, K, self.D, z_e, self.D, q.embedding, self.D, logits, K)
+            call("vqh_softmax_rows", logits, K, None, 1.0, R, K)
+            pc, gk = self.T("ue.pc", K), self.T("ue.g", K)
+            call("vqh_colsum", logits, K, R, K, pc, 0.0, self.ws, self.ws.numel())
+            call("vqh_usage_entropy_finish", pc, K, R, lam, gk, self.metrics, 0, METRIC_KEYS.index("Usage_Reg"))
+            call("vqh_softmax_bwd_colgrad", logits, K, gk, R, K)
+            L.gemm(1, 0, R, self.D, K, logits, K, q.embedding, self.D, d_ze, self.D, beta=1.0)
         if self.ctx is None:
             self.ctx = {}
         self.ctx["d_rec"], self.ctx["d_ze"], self.ctx["weights"] = d_rec, d_ze, dict(weights)
@@ -672,10 +751,10 @@ class StepEngine:
         allreduce_flat(self.flat_gx, include_stats=self._pending_ema is not None, n_grad=self.n_flat)
 
     # ------------------------------------------------------------------ fused training step
-    def _step_part_a(self, x, mask, weights, upd):
+    def _step_part_a(self, x_in, x_tgt, mask, weights, upd):
         self.advance_rng()
-        rec, z_e, z_q, idx, stats = self._forward_core(x, mask, upd)
-        self.loss(rec, x, mask, z_e, z_q, stats, weights)
+        rec, z_e, z_q, idx, stats = self._forward_core(x_in, mask, upd)
+        self.loss(rec, x_tgt, mask, z_e, z_q, stats, weights)
         self.backward()
 
     def _step_part_b(self):
@@ -695,15 +774,18 @@ class StepEngine:
         kernel of the step; for world_size > 1 it is split around the single RCCL all-reduce."""
         m = self.m
         self.train = True
-        self.defer_ema = True
+        self.defer_ema = not (m.use_vq and float(m.usage_entropy_lambda) > 0.0)   # the regulariser reads the refreshed table
+        xt = self.T("in.x", *x.shape)
+        xt.copy_(x, non_blocking=True)
+        x_in = self.augment_input(xt)             # eager, outside the graph (fresh torch random draws every step)
         upd = self._host_prologue()
         world = self.world()
         self.set_hyper(lr, weight_decay, clip, betas=getattr(self, "betas", (0.9, 0.999)), grad_scale=1.0 / world)
         decay = float(m.quantizer.decay) if m.use_vq else 0.0
         key = (tuple(x.shape), mask is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
-               world, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0))
-        xs = self.T("in.x", *x.shape)
-        xs.copy_(x, non_blocking=True)
+               world, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0),
+               x_in is xt, float(m.usage_entropy_lambda), self._soft_vq_key())
+        xs = x_in
         ms = None
         if mask is not None:
             ms = self.T("in.mask", *mask.shape, dtype=torch.bool)
@@ -722,7 +804,7 @@ class StepEngine:
         self._seen[key] = seen + 1
         can_capture = use_graph and seen >= 1 and not (world > 1 and m.use_vq and m.num_quantizers > 1)
         if not can_capture:
-            self._step_part_a(xs, ms, weights, upd)
+            self._step_part_a(xs, xt, ms, weights, upd)
             self.allreduce_grads()
             self._step_part_b()
             return self.metrics
@@ -733,11 +815,11 @@ class StepEngine:
             # thread_local: the RCCL watchdog thread may query events while this thread captures
             if world == 1:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    self._step_part_a(xs, ms, weights, upd)
+                    self._step_part_a(xs, xt, ms, weights, upd)
                     self._step_part_b()
             else:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    self._step_part_a(xs, ms, weights, upd)
+                    self._step_part_a(xs, xt, ms, weights, upd)
                 pend = self._pending_ema
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
@@ -748,7 +830,7 @@ class StepEngine:
             self._seen[key] = -(1 << 30)
             self._pending_ema = None
             torch.cuda.synchronize()
-            self._step_part_a(xs, ms, weights, upd)
+            self._step_part_a(xs, xt, ms, weights, upd)
             self.allreduce_grads()
             self._step_part_b()
             return self.metrics

@@ -34,6 +34,11 @@ _PROTOS = {
     "vqh_add": "ppplp",
     "vqh_copy2d": "pipiiip",
     "vqh_sigmoid_bwd": "ppplp",
+    "vqh_augment": "pppppiip",
+    "vqh_softmax_rows": "pipfiip",
+    "vqh_softmax_bwd_colgrad": "pipiip",
+    "vqh_usage_entropy_finish": "piifppiip",
+    "vqh_vq_mix": "pppfplp",
     "vqh_attn_fwd": "pipipipippiiiiipufp",
     "vqh_attn_bwd": "pipipipippippipipipiiiiipufp",
     "vqh_vq_nearest": "pipipiiiifplp",
@@ -42,8 +47,9 @@ _PROTOS = {
     "vqh_vq_segment_sum": "pipiiiippplp",
     "vqh_vq_ema_apply": "pppppiifffp",
     "vqh_vq_usage_stats": "pifpppp",
+    "vqh_row_sqnorm": "piiipfp",
     "vqh_vq_reinit": "pfppipppiip",
-    "vqh_loss_fwd_bwd": "pppipppiiiiipppppplp",
+    "vqh_loss_fwd_bwd": "pppipppiiiiippppppplp",
     "vqh_grad_norm": "plpppp",
     "vqh_adamw_step": "pppplppp",
 }

@@ -139,7 +139,7 @@ GRAD_KEYS_FULL = ["input_proj.weight", "input_proj.bias", "ss_input_proj.weight"
 
 
 def model_case(name, cfg_kw, B, L, seed, ragged, weights, lr=1e-3, wd=0.01, clip=1.0,
-               smooth=False, steps=1, full_grads=True, eval_too=True):
+               smooth=False, steps=1, full_grads=True, eval_too=True, start_steps=1):
     cfg = O.make_cfg(**cfg_kw)
     sd0 = G.model_state(cfg_kw, seed)
     batches = [(G.smooth_curve_batch if smooth else G.curve_batch)(B, L, seed + 100 + s, ragged)
@@ -148,16 +148,16 @@ def model_case(name, cfg_kw, B, L, seed, ragged, weights, lr=1e-3, wd=0.01, clip
     missing = ref.load_state_dict(sd0, strict=True)          # key/shape compatibility check
     zero_dropout(ref)
     ref.train()
-    ref.training_steps = 1                                   # skip the step-0 grad-summary print
+    ref.training_steps = start_steps                         # >0: skip the step-0 grad-summary print
     opt_r = torch.optim.AdamW(ref.parameters(), lr=lr, weight_decay=wd)
 
     sd = O.attach_grads({k: v.clone() for k, v in sd0.items()}, cfg)
     orc = O.OracleVQVAE(sd, drop_scale=0.0, **cfg_kw)
-    orc.training_steps = 1
+    orc.training_steps = start_steps
     opt_o = torch.optim.AdamW(orc.params(), lr=lr, weight_decay=wd)
 
     out = {"B": B, "L": L, "seed": seed, "ragged": int(ragged), "lr": lr, "wd": wd, "clip": clip,
-           "smooth": int(smooth), "steps": steps, "state_sum": G.checksum(torch.cat([v.reshape(-1) for v in sd0.values()]))}
+           "smooth": int(smooth), "steps": steps, "start_steps": start_steps, "state_sum": G.checksum(torch.cat([v.reshape(-1) for v in sd0.values()]))}
     out["weights_keys"] = np.array(sorted(weights.keys()))
     out["weights_vals"] = np.array([float(weights[k]) for k in sorted(weights.keys())])
     pnames = list(O.param_shapes(cfg).keys())
@@ -236,7 +236,7 @@ def model_case(name, cfg_kw, B, L, seed, ragged, weights, lr=1e-3, wd=0.01, clip
 # ------------------------------------------------------------------------------------------
 # 3. loss function alone, every term switched on, with input gradients
 # ------------------------------------------------------------------------------------------
-def loss_case(name, B, L, seed, ragged, weights, cfg_kw, noise=0.7):
+def loss_case(name, B, L, seed, ragged, weights, cfg_kw, noise=0.7, data_stats=None):
     x, mask = G.smooth_curve_batch(B, L, seed, ragged)
     g = torch.Generator().manual_seed(seed + 1)
     rec = x.clone()
@@ -251,6 +251,11 @@ def loss_case(name, B, L, seed, ragged, weights, cfg_kw, noise=0.7):
     ref.train()
     orc = O.OracleVQVAE({k: v.clone() for k, v in sd0.items()}, drop_scale=0.0, **cfg_kw)
     out = {"B": B, "L": L, "seed": seed, "ragged": int(ragged), "noise": noise}
+    if data_stats is not None:
+        mean, std = torch.tensor(data_stats[0]), torch.tensor(data_stats[1])
+        ref.set_data_stats(mean, std)
+        orc.data_mean, orc.data_std = mean.view(1, 1, 3), std.view(1, 1, 3)
+        out["stats_mean"], out["stats_std"] = np.array(data_stats[0], dtype=np.float32), np.array(data_stats[1], dtype=np.float32)
     for tag, m in (("m", mask), ("nomask", None)):
         if tag == "nomask" and ragged is False:
             pass
@@ -314,6 +319,14 @@ if __name__ == "__main__":
         model_case("model_small_vq_ragged", G.SMALL_VQ, 5, 37, 22, True, G.ALL_LOSS_WEIGHTS, smooth=True, steps=2)
         model_case("model_small_rvq_ragged", G.SMALL_RVQ, 4, 32, 23, True, G.ALL_LOSS_WEIGHTS, smooth=True)
         model_case("model_small_ae", G.SMALL_AE, 8, 40, 24, True, dict(ss_weight=0.6, xyz_tv_lambda=0.006), clip=1.0)
+    if want("extra"):
+        model_case("model_small_softvq", dict(G.SMALL_VQ, soft_vq_use=True, soft_vq_tau_start=2.0, soft_vq_tau_end=0.5,
+                                              soft_vq_tau_warm_steps=10, soft_vq_alpha_warm_steps=20),
+                   5, 24, 41, True, G.BASE_LOSS_WEIGHTS, eval_too=False, start_steps=5)
+        model_case("model_small_uent", dict(G.SMALL_VQ, usage_entropy_lambda=0.05), 5, 24, 42, True, G.BASE_LOSS_WEIGHTS,
+                   eval_too=False)
+        loss_case("loss_datastats", 4, 40, 43, True, G.ALL_LOSS_WEIGHTS, G.SMALL_VQ,
+                  data_stats=([0.3, -0.2, 0.1], [1.7, 0.9, 1.3]))
     if want("c2"):
         model_case("model_c2_b2", G.C2_MODEL, 2, 64, 25, False,
                    dict(G.BASE_LOSS_WEIGHTS, xyz_tv_lambda=0.0008), clip=3.0, lr=2e-4, wd=0.008,

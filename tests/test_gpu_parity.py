@@ -193,7 +193,7 @@ def test_attention_dropout_gradients_match_autograd_with_extracted_mask():
 # ------------------------------------------------------------------------------------------------
 # quantizer against the golden vectors recorded from the reference
 # ------------------------------------------------------------------------------------------------
-from test_oracle import VQ_CASES, vq_setup, MODEL_CASES, model_inputs  # noqa: E402
+from test_oracle import VQ_CASES, vq_setup, MODEL_CASES, EXTRA_CASES, model_inputs  # noqa: E402
 
 
 @pytest.mark.parametrize("name", VQ_CASES)
@@ -246,12 +246,14 @@ def test_quantizer_bit_exact_vs_oracle_at_c2_shape():
 # loss function alone (all 19+5 terms, forward value and input gradients)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,cfg_kw", [("loss_all_ragged", dict(G.SMALL_VQ)), ("loss_all_full", G.SMALL_VQ),
-                                         ("loss_short", G.SMALL_VQ)])
+                                         ("loss_short", G.SMALL_VQ), ("loss_datastats", G.SMALL_VQ)])
 def test_loss_function_matches_reference_golden(name, cfg_kw):
     g = load_golden(name)
     sd0 = G.model_state(cfg_kw, int(g["seed"]))
     m, eng = _model(cfg_kw, sd0)
     m.train()
+    if "stats_std" in g:
+        m.set_data_stats(torch.from_numpy(g["stats_mean"]), torch.from_numpy(g["stats_std"]))
     weights = {k: float(v) for k, v in zip(g["weights_keys"], g["weights_vals"])}
     x, mask = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
     rec, ze, zq = (torch.from_numpy(g[k]).to(DEV) for k in ("recons", "ze", "zq"))
@@ -285,13 +287,13 @@ def _grad_tol(name):
     return 3e-4
 
 
-@pytest.mark.parametrize("name,cfg_kw,_r", MODEL_CASES)
+@pytest.mark.parametrize("name,cfg_kw,_r", MODEL_CASES + EXTRA_CASES)
 def test_train_step_matches_reference_golden(name, cfg_kw, _r):
     g = load_golden(name)
     batches, sd0, weights = model_inputs(g, cfg_kw)
     m, eng = _model(cfg_kw, sd0)
     m.train()
-    m.training_steps = 1
+    m.training_steps = int(g["start_steps"]) if "start_steps" in g else 1
     x, mask = batches[0]
     out = m(x.to(DEV), mask.to(DEV))
     ld = m.loss_function(*out, **weights)
@@ -360,6 +362,45 @@ def test_true_width_c2_model_b2_matches_reference_golden():
     pnames = [str(k) for k in g["param_names"]]
     gne = np.array([float(eng.G[k].norm()) for k in pnames]) * min(1.0, float(g["clip"]) / (float(g["grad_norm_0"]) + 1e-6))
     assert np.allclose(gne, g["gradnorm_each_0"], rtol=3e-3, atol=2e-6 * float(g["grad_norm_0"]))
+
+
+def test_input_augmentation_kernel_and_plumbing():
+    """vqh_augment against the reference formula (_random_rotation :331-345, :775-792) with the same draws; and the
+    model-level plumbing: the target stays un-augmented, SS channels untouched, rotations preserve distances."""
+    L = _hip()
+    torch.manual_seed(11)
+    B, Lq = 5, 17
+    x = torch.randn(B, Lq, 6, device=DEV)
+    u, t = torch.rand(B, 3, device=DEV), torch.randn(B, 3, device=DEV) * 0.02
+    noise = torch.randn(B, Lq, 3, device=DEV) * 0.1
+    out = torch.empty_like(x)
+    L.call("vqh_augment", x, u, t, noise, out, B, Lq)
+    u1, u2, u3 = u[:, 0].double(), u[:, 1].double(), u[:, 2].double()
+    qx, qy = torch.sqrt(1 - u1) * torch.sin(2 * math.pi * u2), torch.sqrt(1 - u1) * torch.cos(2 * math.pi * u2)
+    qz, qw = torch.sqrt(u1) * torch.sin(2 * math.pi * u3), torch.sqrt(u1) * torch.cos(2 * math.pi * u3)
+    R = torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                     2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                     2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)], -1).view(B, 3, 3)
+    want = torch.einsum("bij,blj->bli", R, x[..., :3].double()) + t.double()[:, None] + noise.double()
+    assert rel(out[..., :3], want) < 2e-6 and torch.equal(out[..., 3:], x[..., 3:])
+    from models.vq_vae import VQVAE
+    cfg = dict(G.SMALL_VQ, rigid_aug_prob=1.0, max_noise_std=0.0)
+    m = VQVAE(**cfg)
+    m.load_state_dict(G.model_state(G.SMALL_VQ, 3), strict=True)
+    m = m.to(DEV).train()
+    eng = m._engine()
+    eng.drop_scale = 0.0
+    xb, mask = G.curve_batch(4, 20, 12, ragged=False)
+    outp = m(xb.to(DEV), mask.to(DEV))
+    assert torch.equal(outp[1].cpu(), xb)                               # target is the ORIGINAL input
+    xa = eng.buf["in.x_aug"].cpu()
+    d0 = (xb[:, 1:, :3] - xb[:, :-1, :3]).norm(dim=-1)
+    d1 = (xa[:, 1:, :3] - xa[:, :-1, :3]).norm(dim=-1)
+    assert float((d0 - d1).abs().max()) < 1e-4 and float((xa[..., :3] - xb[..., :3]).abs().max()) > 0.1
+    m.eval()
+    eng.buf.pop("in.x_aug")
+    m(xb.to(DEV), mask.to(DEV))
+    assert "in.x_aug" not in eng.buf                                    # no augmentation in eval mode
 
 
 def test_dead_code_reinit_semantics():

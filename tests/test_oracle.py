@@ -70,6 +70,10 @@ def test_oracle_quantizer_matches_reference(name):
 
 MODEL_CASES = [("model_small_vq_full", G.SMALL_VQ, False), ("model_small_vq_ragged", G.SMALL_VQ, True),
                ("model_small_rvq_ragged", G.SMALL_RVQ, True), ("model_small_ae", G.SMALL_AE, False)]
+SOFTVQ_CFG = dict(G.SMALL_VQ, soft_vq_use=True, soft_vq_tau_start=2.0, soft_vq_tau_end=0.5, soft_vq_tau_warm_steps=10,
+                  soft_vq_alpha_warm_steps=20)
+UENT_CFG = dict(G.SMALL_VQ, usage_entropy_lambda=0.05)
+EXTRA_CASES = [("model_small_softvq", SOFTVQ_CFG, True), ("model_small_uent", UENT_CFG, True)]
 
 
 def model_inputs(g, cfg_kw):
@@ -83,14 +87,14 @@ def model_inputs(g, cfg_kw):
     return batches, sd0, weights
 
 
-@pytest.mark.parametrize("name,cfg_kw,_r", MODEL_CASES)
+@pytest.mark.parametrize("name,cfg_kw,_r", MODEL_CASES + EXTRA_CASES)
 def test_oracle_train_step_matches_reference(name, cfg_kw, _r):
     g = load_golden(name)
     batches, sd0, weights = model_inputs(g, cfg_kw)
     cfg = O.make_cfg(**cfg_kw)
     sd = O.attach_grads({k: v.clone() for k, v in sd0.items()}, cfg)
     orc = O.OracleVQVAE(sd, drop_scale=0.0, **cfg_kw)
-    orc.training_steps = 1
+    orc.training_steps = int(g["start_steps"]) if "start_steps" in g else 1
     opt = torch.optim.AdamW(orc.params(), lr=float(g["lr"]), weight_decay=float(g["wd"]))
     pnames = list(g["param_names"])
     for s, (x, mask) in enumerate(batches):
@@ -132,11 +136,15 @@ def test_oracle_eval_forward_and_decode(name, cfg_kw, _r):
 
 
 @pytest.mark.parametrize("name,cfg_kw", [("loss_all_ragged", dict(G.SMALL_VQ, usage_entropy_lambda=0.01)),
-                                         ("loss_all_full", G.SMALL_VQ), ("loss_short", G.SMALL_VQ)])
+                                         ("loss_all_full", G.SMALL_VQ), ("loss_short", G.SMALL_VQ),
+                                         ("loss_datastats", G.SMALL_VQ)])
 def test_oracle_loss_function_and_input_grads(name, cfg_kw):
     g = load_golden(name)
     sd0 = G.model_state(cfg_kw, int(g["seed"]))
     orc = O.OracleVQVAE(sd0, drop_scale=0.0, **cfg_kw)
+    if "stats_std" in g:
+        orc.data_mean = torch.from_numpy(g["stats_mean"]).view(1, 1, 3)
+        orc.data_std = torch.from_numpy(g["stats_std"]).view(1, 1, 3)
     weights = {k: float(v) for k, v in zip(g["weights_keys"], g["weights_vals"])}
     x, mask = torch.from_numpy(g["x"]), torch.from_numpy(g["mask"])
     B, Nt = g["ze"].shape[:2]
