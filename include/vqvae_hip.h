@@ -53,6 +53,11 @@ int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, 
              float beta, const unsigned long long* rng_state, unsigned drop_site, float drop_p, float* workspace,
              long long workspace_floats, vqh_stream_t stream);
 
+/* dW[n_out,k_in] = dY[rows,n_out]^T . X[rows,k_in]  and  db[n_out] = column sums of dY, one launch (+ split-K reduce):
+ * the autograd weight/bias gradient of every nn.Linear; db may be NULL */
+int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
+                   float* db, float beta, float* workspace, long long workspace_floats, vqh_stream_t stream);
+
 /* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
  * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads) */
 int vqh_gemm_set_flags(int flags);

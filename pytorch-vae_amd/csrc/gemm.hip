@@ -51,6 +51,9 @@ struct GemmArgs {
     int vecA, vecB;        // 16-byte vector loads legal for this operand
     int vecC;              // 16-byte epilogue accesses legal (C, aux, bias aligned; ldc, ldaux multiples of 4)
     float* ws;             // split-K slabs [gridDim.z][M][N] (raw partial sums) or null
+    float* rowsum;         // optional: rowsum[m] = sum_k opA(A)[m,k]  (bias gradient riding on the weight-gradient GEMM;
+                           // only for the [K,M]-stored A layout). With split-K: partials at rowsum_ws[z*M + m].
+    float* rowsum_ws;
     // epilogue
     int mode;
     const float* bias;
@@ -210,6 +213,8 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
 
     f32x4 ra[BKT / 8], rb[BKT / 8];
     const int nk = (kend - kbeg + BKT - 1) / BKT;
+    const bool do_rowsum = (g.rowsum != nullptr) && (n0 == 0);     // one column of tiles carries the row sums
+    float rs_acc = 0.f;
     if (nk > 0) {
         load_tile<A_KC, BKT>(g.A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
         load_tile<B_KC, BKT>(g.B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
@@ -242,11 +247,20 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
         }
+        if (!A_KC && do_rowsum && tid < BM) {
+            // A image is [k][m]: column tid of the tile summed over this K-step (conflict-free: 32 consecutive dwords)
+#pragma unroll
+            for (int k = 0; k < BKT; ++k) rs_acc += a_s[k * BM + tid];
+        }
         if (more) {
             store_tile<A_KC, BKT>(AS(cur ^ 1), tid, ra);
             store_tile<B_KC, BKT>(BS(cur ^ 1), tid, rb);
         }
         __syncthreads();
+    }
+    if (!A_KC && do_rowsum && tid < BM && m0 + tid < g.M) {
+        if (g.rowsum_ws) g.rowsum_ws[(size_t)zsplit * g.M + m0 + tid] = rs_acc;
+        else g.rowsum[m0 + tid] = (g.beta != 0.f) ? g.beta * g.rowsum[m0 + tid] + rs_acc : rs_acc;
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------
@@ -344,10 +358,17 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     }
 }
 
-// Sum split-K slabs, add bias, C = beta*C + sum.  One thread per 4 consecutive columns.
+// Sum split-K slabs, add bias, C = beta*C + sum (+ the row-sum partials of the fused bias gradient).
 __global__ void splitk_reduce(const float* __restrict__ ws, int S, int M, int N, float* __restrict__ C, int ldc,
-                              const float* __restrict__ bias, float beta) {
+                              const float* __restrict__ bias, float beta, const float* __restrict__ rs_ws,
+                              float* __restrict__ rowsum) {
     const size_t total = (size_t)M * N;
+    if (rowsum && blockIdx.x == 0)
+        for (int m = threadIdx.x; m < M; m += blockDim.x) {
+            float s = 0.f;
+            for (int z = 0; z < S; ++z) s += rs_ws[(size_t)z * M + m];
+            rowsum[m] = (beta != 0.f) ? beta * rowsum[m] + s : s;
+        }
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < S; ++z) s += ws[(size_t)z * total + e];
@@ -385,10 +406,10 @@ static int g_gemm_flags = 1;
 extern "C" int vqh_gemm_set_flags(int flags) { const int old = g_gemm_flags; g_gemm_flags = flags; return old; }
 
 // C-ABI: see include/vqvae_hip.h for the contract.
-extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B,
-                        int ldb, float* C, int ldc, const float* bias, int mode, const float* aux_in, float* aux_out,
-                        int ldaux, float beta, const unsigned long long* rng_state, unsigned drop_site, float drop_p,
-                        float* workspace, long long workspace_floats, hipStream_t stream) {
+static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B,
+                     int ldb, float* C, int ldc, const float* bias, int mode, const float* aux_in, float* aux_out,
+                     int ldaux, float beta, const unsigned long long* rng_state, unsigned drop_site, float drop_p,
+                     float* workspace, long long workspace_floats, float* rowsum, hipStream_t stream) {
     VQH_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "vqh_gemm: negative dimension");
     if (M == 0 || N == 0) return VQH_OK;
     VQH_CHECK_ARG(C && ((A && B) || K == 0), "vqh_gemm: null operand");
@@ -415,7 +436,10 @@ extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const
     g.mode = mode; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.beta = beta;
     g.drop.rng_state = rng_state; g.drop.site = drop_site; g.drop.p = drop_p; g.drop.scale = 1.f / (1.f - drop_p);
     g.ws = nullptr;
+    g.rowsum = rowsum;
+    g.rowsum_ws = nullptr;
     g.flags = g_gemm_flags;
+    if (rowsum) VQH_CHECK_ARG(!a_kcontig && mode == EPI_LINEAR, "vqh_gemm_wgrad: row sums need the [K,M] A layout and a linear epilogue");
 
     // split-K when the output has too few tiles to fill 256 CUs (weight gradients: K = B*L rows).
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -424,7 +448,7 @@ extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const
         splits = 512 / tiles;                       // 2 resident blocks per CU x 256 CUs: no tail round
         const int max_by_k = K / (4 * BK);
         if (splits > max_by_k) splits = max_by_k;
-        const long long per = (long long)M * N;
+        const long long per = (long long)M * N + (rowsum ? M : 0);
         if ((long long)splits * per > workspace_floats) splits = (int)(workspace_floats / per);
         if (splits < 2) splits = 1;
     }
@@ -433,7 +457,10 @@ extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const
     splits = (K + kchunk - 1) / kchunk;
     if (splits < 1) splits = 1;
     g.kchunk = kchunk;
-    if (splits > 1) g.ws = workspace;
+    if (splits > 1) {
+        g.ws = workspace;
+        if (rowsum) g.rowsum_ws = workspace + (size_t)splits * M * N;
+    }
 
     int rc;
     if (g.flags & 8) {          // BK=16 variant: 41 KB of LDS, 3 workgroups per CU
@@ -452,8 +479,27 @@ extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const
         const size_t total = (size_t)M * N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, stream, workspace, splits, M, N, C, ldc, bias, beta);
+        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, stream, workspace, splits, M, N, C, ldc, bias, beta,
+                           g.rowsum_ws, rowsum);
         VQH_LAUNCH_CHECK();
     }
     return VQH_OK;
+}
+
+extern "C" int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B,
+                        int ldb, float* C, int ldc, const float* bias, int mode, const float* aux_in, float* aux_out,
+                        int ldaux, float beta, const unsigned long long* rng_state, unsigned drop_site, float drop_p,
+                        float* workspace, long long workspace_floats, hipStream_t stream) {
+    return gemm_impl(a_kcontig, b_kcontig, M, N, K, A, lda, B, ldb, C, ldc, bias, mode, aux_in, aux_out, ldaux, beta,
+                     rng_state, drop_site, drop_p, workspace, workspace_floats, nullptr, stream);
+}
+
+// Weight + bias gradient of a Linear in one launch: dW[Nout,Kin] = dY[rows,Nout]^T . X[rows,Kin] and
+// db[Nout] = column sums of dY (both written as beta*old + value).  dY is the [K,M]-stored A operand.
+extern "C" int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, const float* X, int ldx, float* dW,
+                              int lddw, float* db, float beta, float* workspace, long long workspace_floats,
+                              hipStream_t stream) {
+    if (rows > 0 && n_out > 0 && k_in == 0) return VQH_OK;
+    return gemm_impl(0, 0, n_out, k_in, rows, dY, lddy, X, ldx, dW, lddw, nullptr, EPI_LINEAR, nullptr, nullptr, 0, beta,
+                     nullptr, 0, 0.f, workspace, workspace_floats, db, stream);
 }

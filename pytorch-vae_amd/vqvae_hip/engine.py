@@ -151,10 +151,14 @@ class StepEngine:
         L.gemm(1, 0, rows, K, N, dy, lddy, W, K, dx, lddx, mode=mode, aux_in=aux_in, ldaux=ldaux, beta=beta, p=p)
 
     def lin_wgrad(self, dy, lddy, x, ldx, rows, gW, gb):
-        N, K = gW.shape         # gW[N,K] = dy[rows,N]^T . x[rows,K]
-        L.gemm(0, 0, N, K, rows, dy, lddy, x, ldx, gW, K, ws=self.ws)
-        if gb is not None:
-            call("vqh_colsum", dy, lddy, rows, N, gb, 0.0, self.ws, self.ws.numel())
+        N, K = gW.shape         # gW[N,K] = dy[rows,N]^T . x[rows,K] ; gb[N] = column sums of dy (same launch)
+        if L.PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("vqh_gemm_wgrad", rows, N, K, dy, lddy, x, ldx, gW, K, gb, 0.0, self.ws, self.ws.numel())
+        if L.PROFILE is not None:
+            e1.record()
+            L.PROFILE.append(("0,0", N, K, rows, e0, e1))
 
     def drop_bwd(self, dy, n, site, p, tag):
         """dy * keep-mask of a DROP_RESID site (identity when p == 0)."""

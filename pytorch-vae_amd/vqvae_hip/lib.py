@@ -23,6 +23,7 @@ _PROTOS = {
     "vqh_rng_advance": "pp",
     "vqh_memset": "pilp",
     "vqh_gemm": "iiiiipipipipippifpufplp",
+    "vqh_gemm_wgrad": "iiipipipipfplp",
     "vqh_layernorm_fwd": "pipppippiifp",
     "vqh_layernorm_bwd": "pipippppiippfiiplp",
     "vqh_reduce_slabs": "pillpfp",
