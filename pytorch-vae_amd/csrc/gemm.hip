@@ -141,6 +141,23 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld,
     }
 }
 
+// Same thread->element map as load_tile, for tiles that are completely inside the matrix and 16-byte loadable
+// (the overwhelmingly common case): no per-lane predicates, no scalar fallback -> straight-line loads.
+template <bool KC, int BKT>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ src, int ld, int row0, int k0, int tid,
+                                               f32x4 (&regs)[BKT / 8]) {
+    constexpr int CPR = BKT / 4, RPI = 256 / CPR;
+    if (KC) {
+        const float* p = src + (size_t)(row0 + tid / CPR) * ld + k0 + (tid % CPR) * 4;
+#pragma unroll
+        for (int i = 0; i < BKT / 8; ++i) regs[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(RPI * i) * ld);
+    } else {
+        const float* p = src + (size_t)(k0 + (tid >> 5)) * ld + row0 + (tid & 31) * 4;
+#pragma unroll
+        for (int i = 0; i < BKT / 8; ++i) regs[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(8 * i) * ld);
+    }
+}
+
 template <bool KC, int BKT>
 __device__ __forceinline__ void store_tile(float* __restrict__ lds, int tid, const f32x4 (&regs)[BKT / 8]) {
     constexpr int CPR = BKT / 4, RPI = 256 / CPR, KC_LD = BKT + 4;
@@ -215,9 +232,17 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     const int nk = (kend - kbeg + BKT - 1) / BKT;
     const bool do_rowsum = (g.rowsum != nullptr) && (n0 == 0);     // one column of tiles carries the row sums
     float rs_acc = 0.f;
+    const bool inA = g.vecA && (m0 + BM <= g.M), inB = g.vecB && (n0 + BN <= g.N);   // wave-uniform
+#define LOAD_AB(k0_)                                                                                          \
+    {                                                                                                         \
+        const bool fullk = ((k0_) + BKT <= kend);                                                             \
+        if (inA && fullk) load_tile_fast<A_KC, BKT>(g.A, g.lda, m0, (k0_), tid, ra);                          \
+        else load_tile<A_KC, BKT>(g.A, g.lda, g.M, m0, (k0_), kend, g.vecA, tid, ra);                         \
+        if (inB && fullk) load_tile_fast<B_KC, BKT>(g.B, g.ldb, n0, (k0_), tid, rb);                          \
+        else load_tile<B_KC, BKT>(g.B, g.ldb, g.N, n0, (k0_), kend, g.vecB, tid, rb);                         \
+    }
     if (nk > 0) {
-        load_tile<A_KC, BKT>(g.A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
-        load_tile<B_KC, BKT>(g.B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
+        LOAD_AB(kbeg)
         store_tile<A_KC, BKT>(AS(0), tid, ra);
         store_tile<B_KC, BKT>(BS(0), tid, rb);
     }
@@ -226,10 +251,7 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
-        if (more && !(g.flags & 4)) {
-            load_tile<A_KC, BKT>(g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BKT, kend, g.vecA, tid, ra);
-            load_tile<B_KC, BKT>(g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BKT, kend, g.vecB, tid, rb);
-        }
+        if (more && !(g.flags & 4)) LOAD_AB(kbeg + (kt + 1) * BKT)
         const float* a_s = AS(cur);
         const float* b_s = BS(cur);
 #pragma unroll
@@ -363,12 +385,14 @@ __global__ void splitk_reduce(const float* __restrict__ ws, int S, int M, int N,
                               const float* __restrict__ bias, float beta, const float* __restrict__ rs_ws,
                               float* __restrict__ rowsum) {
     const size_t total = (size_t)M * N;
-    if (rowsum && blockIdx.x == 0)
-        for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    if (rowsum) {      // fused bias gradient: M outputs spread over the first ceil(M/blockDim) blocks
+        const int m = blockIdx.x * blockDim.x + threadIdx.x;
+        if (m < M) {
             float s = 0.f;
             for (int z = 0; z < S; ++z) s += rs_ws[(size_t)z * M + m];
             rowsum[m] = (beta != 0.f) ? beta * rowsum[m] + s : s;
         }
+    }
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < S; ++z) s += ws[(size_t)z * total + e];
@@ -479,6 +503,7 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
         const size_t total = (size_t)M * N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
+        if (rowsum && blocks < (M + 255) / 256) blocks = (M + 255) / 256;
         hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, stream, workspace, splits, M, N, C, ldc, bias, beta,
                            g.rowsum_ws, rowsum);
         VQH_LAUNCH_CHECK();
