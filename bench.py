@@ -156,11 +156,21 @@ def main():
             d[2] += 2.0 * M * N * K
         tot_t = sum(d[1] for d in by.values())
         tot_f = sum(d[2] for d in by.values())
-        dom = max(by, key=lambda k: by[k][1])
+        # the three GEMM variants take about a third of the GEMM time each; report the forward (NT) one, whose event
+        # pair brackets exactly one kernel (the wgrad pair also covers its split-K reduce launch)
+        dom = "1,1" if "1,1" in by else max(by, key=lambda k: by[k][1])
         n, t, f = by[dom]
-        roof = {"bound": "mfma", "kernel": f"gemm_f32_mfma<{dom}>", "achieved": round(f / t / 1e12, 2),
+        traffic = None
+        try:   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")))
+            for kname, d in pm.items():
+                if "gemm_f32_mfma<true, true" in kname and "hbm_bytes_per_launch_corrected" in d:
+                    traffic = d["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
+        roof = {"bound": "mfma", "kernel": f"gemm_f32_mfma<{dom},32>", "achieved": round(f / t / 1e12, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_step": n // 2, "avg_launch_us": round(t / n * 1e6, 2),
+                "traffic": traffic, "launches_per_step": n // 2, "avg_launch_us": round(t / n * 1e6, 2),
                 "gflop_per_launch": round(f / n / 1e9, 3),
                 "all_gemm_variants": {"achieved": round(tot_f / tot_t / 1e12, 2), "time_ms_per_step": round(tot_t / 2 * 1e3, 3),
                                       "gflop_per_step": round(tot_f / 2 / 1e9, 1)},

@@ -44,10 +44,26 @@ struct AttnArgs {
 };
 
 // ---- attention dropout stream ----------------------------------------------------------------------
-// Element (b, head, q, key) has index ((b*nh + head)*T + q) * S4 + key with S4 = S rounded up to 4, so four
-// consecutive keys of one query are ONE Philox evaluation (drop4).  In the query-major kernels a lane holds
-// keys 8g+4h .. +3 of its query in registers 4g..4g+3: one evaluation per register group.
-__device__ __forceinline__ int round4(int s) { return (s + 3) & ~3; }
+// Attention probabilities are dropped with a counter hash instead of Philox: element (row = (b*nh+head)*T + q, key)
+// keeps iff mix32(rowkey(row) ^ key*GOLDEN) * 2^-32 >= p, with rowkey = mix32 chain over (seed, step, site, row).
+// mix32 is the 2-multiply "lowbias32" avalanche hash: ~10 VALU ops per element (Philox4x32-10 cost ~150 per call and
+// made the softmax phase as long as the tile's MFMA time).  Any kernel can evaluate any (row, key) directly, so the
+// forward, dQ and dK/dV kernels regenerate identical masks whatever their register layout.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned attn_rowkey(const DropCfg& d, unsigned long long seed, unsigned long long step,
+                                                unsigned long long row) {
+    unsigned k = mix32((unsigned)seed ^ (d.site * 0x9E3779B9U));
+    k = mix32(k ^ (unsigned)(seed >> 32) ^ ((unsigned)step * 0x85EBCA6BU));
+    k = mix32(k ^ (unsigned)(step >> 32) ^ (unsigned)(row >> 32));
+    return mix32(k ^ (unsigned)row);
+}
+__device__ __forceinline__ float attn_keep(const DropCfg& d, unsigned rowkey, int key) {
+    const unsigned r = mix32(rowkey ^ ((unsigned)key * 0x9E3779B9U));
+    return (r * 2.3283064365386963e-10f >= d.p) ? d.scale : 0.f;
+}
 
 // ---- LDS staging -------------------------------------------------------------------------------
 // A block = 2 waves = 64 rows of one (batch, head).  The other operand (K/V for the query-side kernels, Q/dO
@@ -82,6 +98,7 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_kernel(const AttnArgs a) {
     unsigned long long seed = 0, step = 0;
     if (a.drop.p > 0.f) { seed = a.drop.rng_state[0]; step = a.drop.rng_state[1]; }
 
+    const unsigned rowkey = (a.drop.p > 0.f) ? attn_rowkey(a.drop, seed, step, ((unsigned long long)b * a.nh + hh) * a.T + q) : 0u;
     f32x4 qf[NG];
 #pragma unroll
     for (int t = 0; t < NG; ++t) {
@@ -109,12 +126,13 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
             const float* kr = Ks + (sub * 32 + l31) * LD + 4 * h;
+            f32x4 kfr[NG];                                  // all fragment reads first: one LDS wait per chain, not per MFMA
 #pragma unroll
-            for (int t = 0; t < NG; ++t) {
-                const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + 8 * t);
+            for (int t = 0; t < NG; ++t) kfr[t] = *reinterpret_cast<const f32x4*>(kr + 8 * t);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], sacc, 0, 0, 0);
-            }
+            for (int t = 0; t < NG; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[t][j], qf[t][j], sacc, 0, 0, 0);
             // validity of the tile's 32 keys as a bit mask: one coalesced byte load + ballot, no divergent branches
             const int keyl = s0 + l31;
             const unsigned char vb = (kv && keyl < a.S) ? kv[keyl] : (unsigned char)1;
@@ -144,24 +162,20 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= corr;
             if (a.drop.p > 0.f) {
-                const unsigned long long base = (((unsigned long long)b * a.nh + hh) * a.T + q) * (unsigned long long)round4(a.S);
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float f[4];
-                    drop4(a.drop, seed, step, (base + (unsigned long long)(s0 + 8 * g4 + 4 * h)) >> 2, f);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) p[4 * g4 + e] *= f[e];
-                }
+                for (int r = 0; r < 16; ++r) p[r] *= attn_keep(a.drop, rowkey, s0 + kmap(r, h));
             }
+            float vv[ND][16];
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const int dcol = d * 32 + l31;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float vv = (dcol < DH) ? Vs[(sub * 32 + kmap(r, h)) * LD + dcol] : 0.f;
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[r], o[d], 0, 0, 0);
-                }
+                for (int r = 0; r < 16; ++r) vv[d][r] = (dcol < DH) ? Vs[(sub * 32 + kmap(r, h)) * LD + dcol] : 0.f;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[d][r], p[r], o[d], 0, 0, 0);
         }
     }
     if (q < a.T) {
@@ -209,6 +223,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
     dsum += __shfl_xor(dsum, 32, 64);
     const size_t rowid = ((size_t)b * a.nh + hh) * a.T + q;
+    const unsigned rowkey = (a.drop.p > 0.f) ? attn_rowkey(a.drop, seed, step, (unsigned long long)rowid) : 0u;
     if (qok && h == 0) a.Dsum[rowid] = dsum;
     const float lse = qok ? a.LSE[rowid] : 0.f;
 
@@ -245,13 +260,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             }
             float ds[16], keep[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) keep[r] = 1.f;
-            if (a.drop.p > 0.f) {
-                const unsigned long long base = (((unsigned long long)b * a.nh + hh) * a.T + q) * (unsigned long long)round4(a.S);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    drop4(a.drop, seed, step, (base + (unsigned long long)(s0 + 8 * g4 + 4 * h)) >> 2, &keep[4 * g4]);
-            }
+            for (int r = 0; r < 16; ++r) keep[r] = (a.drop.p > 0.f) ? attn_keep(a.drop, rowkey, s0 + kmap(r, h)) : 1.f;
             const int keyl = s0 + l31;
             const unsigned char vb = (kv && keyl < a.S) ? kv[keyl] : (unsigned char)1;
             const unsigned int vmask = (unsigned int)__ballot((keyl < a.S) && vb != 0);
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(128, 1) void attn_bwd_dkv_kernel(const AttnArgs a) 
     __shared__ __attribute__((aligned(16))) float Qs[64 * LD];
     __shared__ __attribute__((aligned(16))) float Os[64 * LD];
     __shared__ float Ls[64], Ds[64];
+    __shared__ unsigned Rk[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int s0 = blockIdx.x * 64 + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int key = s0 + l31;
@@ -326,6 +336,7 @@ __global__ __launch_bounds__(128, 1) void attn_bwd_dkv_kernel(const AttnArgs a) 
             const int qq = c0 + tid;
             Ls[tid] = (qq < a.T) ? a.LSE[rowbase + qq] : 0.f;
             Ds[tid] = (qq < a.T) ? a.Dsum[rowbase + qq] : 0.f;
+            Rk[tid] = (a.drop.p > 0.f) ? attn_rowkey(a.drop, seed, step, (unsigned long long)(rowbase + qq)) : 0u;
         }
         __syncthreads();
         if (!active) continue;
@@ -351,34 +362,8 @@ __global__ __launch_bounds__(128, 1) void attn_bwd_dkv_kernel(const AttnArgs a) 
             }
             float pd[16], ds[16], keep[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) keep[r] = 1.f;
-            if (a.drop.p > 0.f) {
-                // registers 4g..4g+3 hold queries qg..qg+3 (qg = c0 + sub*32 + 8g + 4h) for THIS lane's key.  Lane i = key&3
-                // evaluates Philox for (query qg+i, key quad of its 4-lane group); round k hands component j=(key&3) of the
-                // evaluation owned by lane (j+k)&3 to lane j: 4 evaluations + 4 shuffles per group instead of 16 evaluations.
-                const int i4 = l31 & 3;
-                const unsigned long long S4 = (unsigned long long)round4(a.S);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int qmine = c0 + sub * 32 + 8 * g4 + 4 * h + i4;
-                    float f[4];
-                    drop4(a.drop, seed, step, (((unsigned long long)(rowbase + qmine)) * S4 + (unsigned long long)(key & ~3)) >> 2, f);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int want = (i4 - k) & 3;          // component the receiver (i4 - k) & 3 needs from me
-                        float send = f[0];
-                        send = (want == 1) ? f[1] : send;
-                        send = (want == 2) ? f[2] : send;
-                        send = (want == 3) ? f[3] : send;
-                        const float got = __shfl(send, (lane & ~3) | ((i4 + k) & 3), 64);
-                        const int e = (i4 + k) & 3;             // the query row this value belongs to
-                        keep[4 * g4 + 0] = (e == 0) ? got : keep[4 * g4 + 0];
-                        keep[4 * g4 + 1] = (e == 1) ? got : keep[4 * g4 + 1];
-                        keep[4 * g4 + 2] = (e == 2) ? got : keep[4 * g4 + 2];
-                        keep[4 * g4 + 3] = (e == 3) ? got : keep[4 * g4 + 3];
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+                keep[r] = (a.drop.p > 0.f) ? attn_keep(a.drop, Rk[sub * 32 + kmap(r, h)], key) : 1.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = sub * 32 + kmap(r, h);
