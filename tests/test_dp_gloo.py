@@ -67,7 +67,8 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch():
     g1, cnt1, sum1, _ = _local(x, mask, G.BASE_LOSS_WEIGHTS)
     assert torch.equal(cnt2, cnt1)                                   # integer counts: exactly additive
     assert float((sum2.reshape(-1) - sum1.reshape(-1)).abs().max()) <= 1e-5 * float(sum1.abs().max())
-    assert float((g2 - g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+    # mean of shard means vs mean over the full batch: fp32 summation-order noise only
+    assert float((g2 - g1).abs().max()) <= 1e-4 * float(g1.abs().max())
 
 
 def test_shard_bounds():

@@ -176,11 +176,14 @@ def test_oracle_state_dict_layout_matches_reference_keys():
 @pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="reference tree absent (GPU box)")
 def test_oracle_matches_live_reference_with_dropout_off():
     """Build container only: a fresh comparison against the imported reference on a new seed."""
-    import sys
-    sys.path.insert(0, "/root/reference")
+    import importlib.util
     import warnings
     warnings.filterwarnings("ignore")
-    from models.vq_vae import VQVAE as Ref
+    # load the reference module under its own name: `models` may already be OUR package in this process
+    spec = importlib.util.spec_from_file_location("reference_vq_vae", "/root/reference/models/vq_vae.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    Ref = mod.VQVAE
     cfg_kw = dict(G.SMALL_VQ)
     sd0 = G.model_state(cfg_kw, 777)
     ref = Ref(**cfg_kw)
