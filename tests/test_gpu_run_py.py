@@ -1,0 +1,67 @@
+# -*- coding: utf-8 -*-
+"""-m gpu: the drop-in entry (pytorch-vae_amd/run.py, same flags as the reference run.py:97-106) end to end on the HIP
+model with synthetic curves: stage 1 (AE) -> checkpoint -> stage 2 (VQ) with --warm_start_ckpt (quantizer.* dropped)
+and --init_codebook -> --resume_ckpt.  Two-stage config C4's flow at a small width."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import PKG
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(hidden_dim=64, num_layers=1, num_heads=4, tokenizer_heads=4, tokenizer_layers=1, max_seq_len=48,
+             code_dim=16, latent_tokens=8)
+
+
+def _cfg(base, tmp, name, **over):
+    cfg = yaml.safe_load(open(os.path.join(PKG, "configs", base)))
+    cfg["model_params"].update(SMALL)
+    cfg["model_params"].update(over.pop("model", {}))
+    cfg["data_params"].update(train_batch_size=16, val_batch_size=16, num_workers=0, pin_memory=False,
+                              synthetic={"n": 64, "n_val": 16, "max_len": 48, "min_len": 30, "seed": 3})
+    cfg["exp_params"].update(checkpoint_dir=os.path.join(tmp, name), save_every_epochs=1, print_every=2)
+    cfg["exp_params"].update(over.pop("exp", {}))
+    cfg["trainer_params"].update(max_epochs=over.pop("epochs", 2), devices=1, limit_val_batches=1.0)
+    path = os.path.join(tmp, name + ".yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    return path
+
+
+def _run(args):
+    env = dict(os.environ, PYTHONPATH=PKG)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "run.py")] + args, cwd=PKG, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_two_stage_training_through_run_py(tmp_path):
+    tmp = str(tmp_path)
+    s1 = _cfg("stage1_ae.yaml", tmp, "s1")
+    out1 = _run(["-c", s1])
+    assert "[Epoch 1]" in out1 and "Training VQVAE-AEStage1" in out1
+    ck1 = os.path.join(tmp, "s1", "last.ckpt")
+    c1 = torch.load(ck1, map_location="cpu", weights_only=True)
+    assert c1["epoch"] == 1 and all(k.startswith("model.") for k in c1["state_dict"]) and "optimizer_states" in c1
+    assert not any(k.startswith("model.quantizer.") for k in c1["state_dict"])            # stage 1 has no quantizer
+    cents = os.path.join(tmp, "centroids.npy")
+    np.save(cents, (np.random.RandomState(0).randn(2, 32, 16) * 0.1).astype(np.float32))   # [levels, K_per, D]
+    s2 = _cfg("stage2_vq.yaml", tmp, "s2", model=dict(num_quantizers=2, codebook_size=32), epochs=2)
+    out2 = _run(["-c", s2, "--warm_start_ckpt", ck1, "--init_codebook", cents])
+    assert "[WarmStart] loaded kept=" in out2 and "[Codebook Init] Loaded centroids" in out2 and "[Epoch 1]" in out2
+    ck2 = os.path.join(tmp, "s2", "last.ckpt")
+    c2 = torch.load(ck2, map_location="cpu", weights_only=True)
+    assert c2["state_dict"]["model.quantizer.embedding"].shape == (64, 16)
+    # encoder weights came from stage 1 and were then trained: same shape, finite
+    assert all(torch.isfinite(v).all() for v in c2["state_dict"].values() if v.dtype.is_floating_point)
+    # resume: one more epoch from the saved state (optimizer moments + LR position restored)
+    s2b = _cfg("stage2_vq.yaml", tmp, "s2", model=dict(num_quantizers=2, codebook_size=32), epochs=3)
+    out3 = _run(["-c", s2b, "--resume_ckpt", ck2])
+    assert "[Resume]" in out3 and "[Epoch 2]" in out3 and "[Epoch 1]" not in out3
+    c3 = torch.load(ck2, map_location="cpu", weights_only=True)
+    assert c3["epoch"] == 2 and c3["global_step"] > c2["global_step"]
