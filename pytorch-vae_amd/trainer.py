@@ -52,9 +52,10 @@ class Trainer:
         if self.world_size > 1 and not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = "nccl" if (self.accelerator == "gpu" and torch.cuda.is_available()) else "gloo"
+            backend = os.environ.get("VQH_DIST_BACKEND", backend)     # tests: several ranks sharing one GPU need gloo
             torch.distributed.init_process_group(backend, rank=self.global_rank, world_size=self.world_size)
         if self.accelerator == "gpu" and torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
 
     def _limit(self, n, lim):
         return max(1, int(n * lim)) if isinstance(lim, float) and lim <= 1.0 else min(n, int(lim))
@@ -65,7 +66,7 @@ class Trainer:
         exp.trainer, exp.global_rank = self, self.global_rank
         self.ckpt_path = ckpt_path
         if self.accelerator == "gpu":
-            exp.model = exp.model.to(torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))))
+            exp.model = exp.model.to(torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()))
         exp.setup("fit")
         policy = exp.configure_optimizers()
         start_epoch = 0

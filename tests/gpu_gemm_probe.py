@@ -7,7 +7,7 @@ from vqvae_hip import lib as L
 torch.manual_seed(0)
 dev = "cuda"
 ws = torch.empty(64 * 1024 * 1024, device=dev)
-SHAPES = [(1,1,16384,512,512),(1,1,16384,1536,512),(1,1,16384,2048,512),(1,1,16384,512,2048),
+SHAPES = [(1,0,16384,512,512),(1,0,16384,1536,512),(1,0,16384,64,512),(1,1,16384,64,512),(1,1,16384,512,512),(1,1,16384,1536,512),(1,1,16384,2048,512),(1,1,16384,512,2048),
           (1,0,16384,512,2048),(1,0,16384,2048,512),(1,0,16384,512,1536),(0,0,512,512,16384),(0,0,2048,512,16384),(0,0,512,2048,16384),(0,0,1536,512,16384)]
 
 def timeit(akc, bkc, M, N, K, iters=20):
