@@ -30,23 +30,70 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ X, int ld, int rows,
     if (lane == 0) out[row] = s * scale;
 }
 
-// one wave per 32 rows; codes in tiles of 32; D multiple of 8.
+// ---- duplicate codes --------------------------------------------------------------------------------
+// Identical codebook rows (e.g. the hundreds of all-zero rows a fresh EMA table has after its first refresh) give
+// bit-identical scores, i.e. exact ties that torch.argmin resolves to the lowest index.  They must not count as
+// "ambiguous" (the refinement re-reads the whole table per flagged row).  canon[k] = lowest index j <= k whose row
+// equals row k; a candidate only competes for "second best" if its canonical index differs from the best's.
+__global__ void code_hash_kernel(const float* __restrict__ E, int lde, int K, int D, unsigned long long* __restrict__ hash) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    unsigned long long h = 0;
+    for (int i = lane; i < D; i += 64) {
+        float v = E[(size_t)k * lde + i];
+        if (v == 0.f) v = 0.f;                                    // -0 and +0 score identically
+        unsigned x = __float_as_uint(v) ^ ((unsigned)i * 0x9E3779B9U);
+        x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+        h += ((unsigned long long)x << 17) ^ (unsigned long long)(x * 0x85EBCA6BU);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    if (lane == 0) hash[k] = h;
+}
+// one wave per code k: lanes scan the hashes of codes j < k, 64 at a time, in ascending order; the first hash match
+// that is a true row match (verified by the whole wave) is the canonical index.
+__global__ __launch_bounds__(256) void code_canon_kernel(const unsigned long long* __restrict__ hash,
+                                                         const float* __restrict__ E, int lde, int K, int D,
+                                                         int* __restrict__ canon) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    const unsigned long long hk = hash[k];
+    int c = k;
+    for (int base = 0; base < k && c == k; base += 64) {
+        const int j = base + lane;
+        unsigned long long m = __ballot(j < k && hash[j] == hk);
+        while (m) {
+            const int jj = base + __ffsll((long long)m) - 1;
+            m &= m - 1;
+            bool same = true;
+            for (int i = lane; i < D; i += 64) same = same && (E[(size_t)jj * lde + i] == E[(size_t)k * lde + i]);
+            if (__all(same)) { c = jj; break; }
+        }
+    }
+    if (lane == 0) canon[k] = c;
+}
+
+// one wave per (32 rows, code range): codes in tiles of 32, D multiple of 8.  blockIdx.y selects a contiguous range
+// of codes so that small R with large K still fills the chip; partial (best, second, index) triples are merged in
+// code order by vq_combine_kernel (ties -> lower index, like torch.argmin).
 __global__ __launch_bounds__(64, 2) void vq_nearest_kernel(const float* __restrict__ Z, int ldz,
                                                            const float* __restrict__ E, int lde,
                                                            const float* __restrict__ enorm,
-                                                           const float* __restrict__ znorm,
-                                                           long long* __restrict__ idx_out, int idx_offset,
-                                                           unsigned char* __restrict__ ambiguous, int R, int K, int D,
-                                                           float rel_tol) {
+                                                           const int* __restrict__ canon, float* __restrict__ pbest,
+                                                           float* __restrict__ psecond, int* __restrict__ pidx, int R,
+                                                           int K, int D, int kchunk) {
     const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * 32;
     const int row = r0 + l31;
     const bool rok = row < R;
     const float* zp = Z + (size_t)row * ldz;
     float best = INFINITY, second = INFINITY;
-    int bidx = 0x7fffffff;
+    int bidx = 0x7fffffff, bcan = -1;
     const int ng = D / 8;
-    for (int c0 = 0; c0 < K; c0 += 32) {
+    const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+    for (int c0 = kbeg; c0 < kend; c0 += 32) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -54,7 +101,7 @@ __global__ __launch_bounds__(64, 2) void vq_nearest_kernel(const float* __restri
         const float* ep = E + (size_t)code_l * lde;
         for (int t = 0; t < ng; ++t) {
             f32x4 ef = {0.f, 0.f, 0.f, 0.f}, zf = {0.f, 0.f, 0.f, 0.f};
-            if (code_l < K) ef = *reinterpret_cast<const f32x4*>(ep + 8 * t + 4 * h);
+            if (code_l < kend) ef = *reinterpret_cast<const f32x4*>(ep + 8 * t + 4 * h);
             if (rok) zf = *reinterpret_cast<const f32x4*>(zp + 8 * t + 4 * h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[j], zf[j], acc, 0, 0, 0);
@@ -63,55 +110,104 @@ __global__ __launch_bounds__(64, 2) void vq_nearest_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int code = c0 + kmap(r, h);
-            if (code < K) {
+            if (code < kend) {
                 const float d = enorm[code] - 2.f * acc[r];
                 if (d < best) {
                     second = best;
                     best = d;
                     bidx = code;
+                    bcan = canon[code];
                 } else if (d < second) {
-                    second = d;
+                    if (!(d == best && canon[code] == bcan)) second = d;    // an exact duplicate of the best is not a rival
                 }
             }
         }
     }
     // combine the two lane halves (same row, disjoint code subsets)
     const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
-    const int oi = __shfl_xor(bidx, 32, 64);
+    const int oi = __shfl_xor(bidx, 32, 64), oc = __shfl_xor(bcan, 32, 64);
+    const bool dup = (ob == best) && (oc == bcan);
     float fb, fs;
     int fi;
     if (ob < best || (ob == best && oi < bidx)) {
-        fb = ob; fi = oi; fs = fminf(best, os);
+        fb = ob; fi = oi; fs = dup ? fminf(second, os) : fminf(best, os);
     } else {
-        fb = best; fi = bidx; fs = fminf(ob, second);
+        fb = best; fi = bidx; fs = dup ? fminf(second, os) : fminf(ob, second);
     }
     if (rok && h == 0) {
-        idx_out[row] = (long long)fi + idx_offset;
-        const float scale = znorm[row] + fabsf(fb) + 1e-30f;
-        ambiguous[row] = ((fs - fb) <= rel_tol * scale) ? 1 : 0;
+        const size_t o = (size_t)blockIdx.y * R + row;
+        pbest[o] = fb;
+        psecond[o] = fs;
+        pidx[o] = fi;
     }
 }
 
-// exact re-evaluation of flagged rows: fp64 direct form, lowest index wins ties. One wave per row.
+// merge the per-range partials (ascending code ranges), write the index and flag rows whose top-2 gap is inside the
+// fp32 noise band; bestval keeps the winning score for the refinement's pre-filter.
+__global__ void vq_combine_kernel(const float* __restrict__ pbest, const float* __restrict__ psecond,
+                                  const int* __restrict__ pidx, const int* __restrict__ canon, int nsplit,
+                                  const float* __restrict__ znorm,
+                                  long long* __restrict__ idx_out, int idx_offset, unsigned char* __restrict__ ambiguous,
+                                  float* __restrict__ bestval, int R, float rel_tol) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    float fb = INFINITY, fs = INFINITY;
+    int fi = 0x7fffffff;
+    for (int s = 0; s < nsplit; ++s) {
+        const size_t o = (size_t)s * R + row;
+        const float b = pbest[o], sc = psecond[o];
+        const int i = pidx[o];
+        if (i == 0x7fffffff) continue;
+        const bool dup = (fi != 0x7fffffff) && (b == fb) && (canon[i] == canon[fi]);
+        if (b < fb || (b == fb && i < fi)) {
+            fs = dup ? fminf(fs, sc) : fminf(fb, fminf(fs, sc));
+            fb = b;
+            fi = i;
+        } else {
+            fs = dup ? fminf(fs, sc) : fminf(fs, b);
+        }
+    }
+    idx_out[row] = (long long)fi + idx_offset;
+    const float scale = znorm[row] + fabsf(fb) + 1e-30f;
+    ambiguous[row] = ((fs - fb) <= rel_tol * scale) ? 1 : 0;
+    bestval[row] = fb;
+}
+
+// exact re-evaluation of flagged rows, lowest index wins ties.  One wave per row.  Every code is first scored with the
+// fp32 direct form sum (z-e)^2 (4 independent accumulators); only codes within the noise band of the provisional
+// best are re-evaluated in fp64, so the cost is an fp32 scan plus a handful of fp64 rows.
 __global__ __launch_bounds__(256) void vq_refine_kernel(const float* __restrict__ Z, int ldz,
                                                         const float* __restrict__ E, int lde,
                                                         long long* __restrict__ idx_out, int idx_offset,
-                                                        const unsigned char* __restrict__ ambiguous, int R, int K,
-                                                        int D) {
+                                                        const unsigned char* __restrict__ ambiguous,
+                                                        const float* __restrict__ znorm,
+                                                        const float* __restrict__ bestval, int R, int K, int D,
+                                                        float rel_tol) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R || !ambiguous[row]) return;
     const float* zp = Z + (size_t)row * ldz;
+    const float zn = znorm[row];
+    const float scale = zn + fabsf(bestval[row]) + 1e-30f;
+    const float thr = (zn + bestval[row]) + 4.f * rel_tol * scale;      // provisional best distance + a generous band
     double best = 1e300;
     int bidx = 0x7fffffff;
     for (int k = lane; k < K; k += 64) {
         const float* ep = E + (size_t)k * lde;
-        double s = 0.0;
-        for (int i = 0; i < D; ++i) {
-            const double d = (double)zp[i] - (double)ep[i];
-            s += d * d;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int i = 0; i < D; i += 4) {
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(zp + i), ev = *reinterpret_cast<const f32x4*>(ep + i);
+            const f32x4 d = zv - ev;
+            s0 += d[0] * d[0]; s1 += d[1] * d[1]; s2 += d[2] * d[2]; s3 += d[3] * d[3];
         }
-        if (s < best) { best = s; bidx = k; }
+        if ((s0 + s1) + (s2 + s3) <= thr) {
+            double s = 0.0;
+            for (int i = 0; i < D; ++i) {
+                const double d = (double)zp[i] - (double)ep[i];
+                s += d * d;
+            }
+            if (s < best) { best = s; bidx = k; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -119,7 +215,7 @@ __global__ __launch_bounds__(256) void vq_refine_kernel(const float* __restrict_
         const int oi = __shfl_xor(bidx, o, 64);
         if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
     }
-    if (lane == 0) idx_out[row] = (long long)bidx + idx_offset;
+    if (lane == 0 && bidx != 0x7fffffff) idx_out[row] = (long long)bidx + idx_offset;
 }
 
 // z_q = E[idx - idx_offset]; z_st = z + (z_q - z); zq_acc (+)= z_q ; res_out = res_in - z_q
@@ -336,7 +432,7 @@ inline int blocks_for(long long n) {
 
 }  // namespace
 
-// workspace: K (code norms) + R (row norms) floats, + R bytes (ambiguity flags) -> (K + R + R/4 + 1) floats
+// workspace (floats): K code norms + R row norms + R best scores + nsplit*R*(best, second, index) + R/4 flag bytes
 extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset,
                               int R, int K, int D, float rel_tol, float* workspace, long long workspace_floats,
                               hipStream_t stream) {
@@ -345,16 +441,37 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     VQH_CHECK_ARG(Z && E && idx_out && workspace, "vqh_vq_nearest: null pointer");
     VQH_CHECK_ARG(((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(E)) & 15) == 0 && (ldz & 3) == 0 && (lde & 3) == 0,
                   "vqh_vq_nearest: operands must be 16-byte aligned");
-    VQH_CHECK_ARG((long long)K + R + (R + 3) / 4 + 1 <= workspace_floats, "vqh_vq_nearest: workspace too small");
-    float* enorm = workspace;
-    float* znorm = workspace + K;
-    unsigned char* amb = reinterpret_cast<unsigned char*>(workspace + K + R);
+    const int row_blocks = (R + 31) / 32;
+    int nsplit = 1;                              // fill ~2048 waves: split the code range when there are few rows
+    if (row_blocks < 1024) {
+        nsplit = (2048 + row_blocks - 1) / row_blocks;
+        const int max_split = (K + 255) / 256;   // at least 256 codes per range
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+    }
+    int kchunk = ((K + nsplit - 1) / nsplit + 31) / 32 * 32;
+    nsplit = (K + kchunk - 1) / kchunk;
+    const long long need = 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8;
+    VQH_CHECK_ARG(need <= workspace_floats, "vqh_vq_nearest: workspace too small");
+    unsigned long long* hash = reinterpret_cast<unsigned long long*>(workspace);      // 2K floats, 8-byte aligned
+    int* canon = reinterpret_cast<int*>(workspace + 2 * (size_t)K);
+    float* enorm = workspace + 3 * (size_t)K;
+    float* znorm = enorm + K;
+    float* bestval = znorm + R;
+    float* pbest = bestval + R;
+    float* psecond = pbest + (size_t)nsplit * R;
+    int* pidx = reinterpret_cast<int*>(psecond + (size_t)nsplit * R);
+    unsigned char* amb = reinterpret_cast<unsigned char*>(pidx + (size_t)nsplit * R);
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, enorm, 1.f);
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, R, D, znorm, 1.f);
-    hipLaunchKernelGGL(vq_nearest_kernel, dim3((R + 31) / 32), dim3(64), 0, stream, Z, ldz, E, lde, enorm, znorm, idx_out,
-                       idx_offset, amb, R, K, D, rel_tol);
+    hipLaunchKernelGGL(code_hash_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, hash);
+    hipLaunchKernelGGL(code_canon_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, hash, E, lde, K, D, canon);
+    hipLaunchKernelGGL(vq_nearest_kernel, dim3(row_blocks, nsplit), dim3(64), 0, stream, Z, ldz, E, lde, enorm, canon, pbest,
+                       psecond, pidx, R, K, D, kchunk);
+    hipLaunchKernelGGL(vq_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, pbest, psecond, pidx, canon, nsplit, znorm,
+                       idx_out, idx_offset, amb, bestval, R, rel_tol);
     hipLaunchKernelGGL(vq_refine_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, E, lde, idx_out, idx_offset, amb,
-                       R, K, D);
+                       znorm, bestval, R, K, D, rel_tol);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
