@@ -70,11 +70,11 @@ __device__ __forceinline__ float attn_keep(const DropCfg& d, unsigned rowkey, in
 // for the key-side kernel) is staged 64 rows at a time into LDS with coalesced 16-byte loads issued in bulk,
 // then every MFMA fragment comes from LDS:  [row][DH+4] floats (row stride == 4 mod 64 dwords: the 16-lane
 // groups of ds_read_b128 cover all 64 banks; the transposed operand reads 32 consecutive dwords per half).
-template <int DH>
+template <int DH, int NT>
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int ld, int row0,
                                            int nrows_total, int tid) {
     constexpr int LD = DH + 4, C4 = DH / 4;
-    for (int i = tid; i < 64 * C4; i += 128) {
+    for (int i = tid; i < 64 * C4; i += NT) {
         const int r = i / C4, c = (i % C4) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row0 + r < nrows_total) v = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + r) * ld + c);
@@ -82,13 +82,13 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
     }
 }
 
-template <int DH>
-__global__ __launch_bounds__(128, 2) void attn_fwd_kernel(const AttnArgs a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
     __shared__ __attribute__((aligned(16))) float Ks[64 * LD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 64 + wave * 32, hh = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
     const bool active = q0 < a.T;
     const float* Qp = a.Q + ((size_t)b * a.T + q) * a.ldq + hh * DH;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_kernel(const AttnArgs a) {
 
     for (int c0 = 0; c0 < a.S; c0 += 64) {
         __syncthreads();
-        stage_rows<DH>(Ks, Kb, a.ldk, c0, a.S, tid);
-        stage_rows<DH>(Vs, Vb, a.ldv, c0, a.S, tid);
+        stage_rows<DH, 64 * NW>(Ks, Kb, a.ldk, c0, a.S, tid);
+        stage_rows<DH, 64 * NW>(Vs, Vb, a.ldv, c0, a.S, tid);
         __syncthreads();
         if (!active) continue;
 #pragma unroll
@@ -193,13 +193,13 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_kernel(const AttnArgs a) {
 }
 
 // dQ (and D = rowsum(dO*O)) : one wave per 32 queries (2 per block), K/V staged through LDS.
-template <int DH>
-__global__ __launch_bounds__(128, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
     __shared__ __attribute__((aligned(16))) float Ks[64 * LD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 64 + wave * 32, hh = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
     const bool qok = q < a.T, active = q0 < a.T;
     const float* Qp = a.Q + ((size_t)b * a.T + q) * a.ldq + hh * DH;
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 
     for (int c0 = 0; c0 < a.S; c0 += 64) {
         __syncthreads();
-        stage_rows<DH>(Ks, Kb, a.ldk, c0, a.S, tid);
-        stage_rows<DH>(Vs, Vb, a.ldv, c0, a.S, tid);
+        stage_rows<DH, 64 * NW>(Ks, Kb, a.ldk, c0, a.S, tid);
+        stage_rows<DH, 64 * NW>(Vs, Vb, a.ldv, c0, a.S, tid);
         __syncthreads();
         if (!active) continue;
 #pragma unroll
@@ -295,15 +295,15 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 // dK, dV : one wave per 32 keys (2 per block); Q / dO / LSE / D of 64 queries at a time staged through LDS.
-template <int DH>
-__global__ __launch_bounds__(128, 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
     constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
     __shared__ __attribute__((aligned(16))) float Qs[64 * LD];
     __shared__ __attribute__((aligned(16))) float Os[64 * LD];
     __shared__ float Ls[64], Ds[64];
     __shared__ unsigned Rk[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int s0 = blockIdx.x * 64 + wave * 32, hh = blockIdx.y, b = blockIdx.z;
+    const int s0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int key = s0 + l31;
     const bool active = s0 < a.S;
     const float* Qb = a.Q + (size_t)b * a.T * a.ldq + hh * DH;
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(128, 1) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const size_t rowbase = ((size_t)b * a.nh + hh) * a.T;
     for (int c0 = 0; c0 < a.T; c0 += 64) {
         __syncthreads();
-        stage_rows<DH>(Qs, Qb, a.ldq, c0, a.T, tid);
-        stage_rows<DH>(Os, dOb, a.lddo, c0, a.T, tid);
+        stage_rows<DH, 64 * NW>(Qs, Qb, a.ldq, c0, a.T, tid);
+        stage_rows<DH, 64 * NW>(Os, dOb, a.lddo, c0, a.T, tid);
         if (tid < 64) {
             const int qq = c0 + tid;
             Ls[tid] = (qq < a.T) ? a.LSE[rowbase + qq] : 0.f;
@@ -430,12 +430,18 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE;
     a.kvalid = kvalid; a.B = B; a.nh = nh; a.T = T; a.S = S; a.scale = 1.0f / sqrtf((float)dh);
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
-    dim3 grid((T + 63) / 64, nh, B);
+    // 4 waves (128 queries) share each staged K/V chunk when there are enough queries per (batch, head)
+    const int NWq = (T >= 128) ? 4 : 2;
+    dim3 grid((T + 32 * NWq - 1) / (32 * NWq), nh, B);
+#define FWD(DH_)                                                                                         \
+    if (NWq == 4) hipLaunchKernelGGL((attn_fwd_kernel<DH_, 4>), grid, dim3(256), 0, stream, a);           \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH_, 2>), grid, dim3(128), 0, stream, a)
     switch (dh) {
-        case 16: hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(128), 0, stream, a); break;
-        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(128), 0, stream, a); break;
-        default: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(128), 0, stream, a); break;
+        case 16: FWD(16); break;
+        case 32: FWD(32); break;
+        default: FWD(64); break;
     }
+#undef FWD
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
@@ -459,21 +465,19 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     a.scale = 1.0f / sqrtf((float)dh);
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
     a.dO = dO; a.lddo = lddo; a.Dsum = Dsum; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
-    dim3 gq((T + 63) / 64, nh, B), gk((S + 63) / 64, nh, B);
+    const int NWq = (T >= 128) ? 4 : 2, NWk = (S >= 128) ? 4 : 2;
+    dim3 gq((T + 32 * NWq - 1) / (32 * NWq), nh, B), gk((S + 32 * NWk - 1) / (32 * NWk), nh, B);
+#define BWD(DH_)                                                                                          \
+    if (NWq == 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH_, 4>), gq, dim3(256), 0, stream, a);           \
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH_, 2>), gq, dim3(128), 0, stream, a);                    \
+    if (NWk == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH_, 4>), gk, dim3(256), 0, stream, a);          \
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH_, 2>), gk, dim3(128), 0, stream, a)
     switch (dh) {
-        case 16:
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, gq, dim3(128), 0, stream, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<16>, gk, dim3(128), 0, stream, a);
-            break;
-        case 32:
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(128), 0, stream, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(128), 0, stream, a);
-            break;
-        default:
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(128), 0, stream, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(128), 0, stream, a);
-            break;
+        case 16: BWD(16); break;
+        case 32: BWD(32); break;
+        default: BWD(64); break;
     }
+#undef BWD
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
