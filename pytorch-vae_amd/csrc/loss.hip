@@ -821,8 +821,9 @@ extern "C" int vqh_loss_fwd_bwd(const float* recons, const float* target, const 
     VQH_CHECK_ARG(smem <= 160 * 1024, "vqh_loss_fwd_bwd: sequence too long for the LDS-resident loss kernel");
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_sample_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) { vqh_set_error(hipGetErrorString(ea)); return VQH_ERR_LAUNCH; }
         attr_set = true;
     }
     hipLaunchKernelGGL(loss_sample_kernel, dim3(B), dim3(256), smem, stream, recons, target, mask, ze, zq, table, c,

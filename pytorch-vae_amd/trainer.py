@@ -8,7 +8,6 @@ Lightning-layout checkpoints:
 so a checkpoint written here loads through the reference's warm-start code (it strips the "model." prefix,
 run.py:63-69) and vice versa."""
 import os
-import time
 from typing import List, Optional
 
 import torch

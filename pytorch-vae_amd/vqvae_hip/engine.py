@@ -18,14 +18,11 @@ Memory layout in HBM (all fp32, row-major):
     attention reads heads in place from the packed QKV projection (no head transposes)
   * residual-stream gradient: one [rows, H] buffer per stack, updated in place layer by layer
 """
-import math
-
 import torch
 
 from . import lib as L
 from .lib import call
 
-FF = 2048            # torch default dim_feedforward of nn.Transformer{Encoder,Decoder}Layer
 SS_LAYERS = 2        # models/vq_vae.py:473
 LN_EPS = 1e-5
 VQ_EPS = 1e-5
