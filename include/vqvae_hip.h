@@ -103,13 +103,17 @@ int vqh_vq_mix(const float* ze, const float* zsoft, const float* zhard, float al
                vqh_stream_t stream);
 
 /* nn.MultiheadAttention core (scaled scores, key padding mask, softmax, dropout, P.V), flash style.
- * Q/K/V/O element (b, t, head, d) at ptr[(b*T + t)*ld + head*dh + d]; kvalid [B,S] bytes (1 = attend) or NULL. */
+ * Q/K/V/O element (b, t, head, d) at ptr[(b*T + t)*ld + head*dh + d]; kvalid [B,S] bytes (1 = attend) or NULL.
+ * qkv_shared bit 0: Q holds ONE sample ([T, ldq]) shared by all B batch entries; bit 1: the same for K and V ([S, ld]).
+ * The first decoder layer sees the same query_embed+pos_enc rows for every sample (models/vq_vae.py:750-751) and the
+ * first tokenizer layer the same learned queries (:313), so their projections are computed once; outputs and the
+ * gradients dQ/dK/dV stay per sample. */
 int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
-                 float* LSE, const unsigned char* kvalid, int B, int nh, int T, int S, int dh,
+                 float* LSE, const unsigned char* kvalid, int B, int nh, int T, int S, int dh, int qkv_shared,
                  const unsigned long long* rng_state, unsigned drop_site, float drop_p, vqh_stream_t stream);
 int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                  const float* LSE, const float* dO, int lddo, float* Dsum, float* dQ, int lddq, float* dK, int lddk,
-                 float* dV, int lddv, const unsigned char* kvalid, int B, int nh, int T, int S, int dh,
+                 float* dV, int lddv, const unsigned char* kvalid, int B, int nh, int T, int S, int dh, int qkv_shared,
                  const unsigned long long* rng_state, unsigned drop_site, float drop_p, vqh_stream_t stream);
 
 /* VectorQuantizerEMA (models/vq_vae.py:19-283) */

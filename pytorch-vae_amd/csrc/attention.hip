@@ -33,6 +33,7 @@ struct AttnArgs {
     float* LSE;                   // [B, nh, T]
     const unsigned char* kvalid;  // [B, S] 1 = attend, 0 = padded key; null = all valid
     int B, nh, T, S;
+    long long qbs, kbs, vbs;      // batch strides (elements) of the Q / K / V INPUTS; 0 = one copy shared by every sample
     float scale;
     DropCfg drop;
     // backward
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) 
     const int q0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
     const bool active = q0 < a.T;
-    const float* Qp = a.Q + ((size_t)b * a.T + q) * a.ldq + hh * DH;
-    const float* Kb = a.K + (size_t)b * a.S * a.ldk + hh * DH;
-    const float* Vb = a.V + (size_t)b * a.S * a.ldv + hh * DH;
+    const float* Qp = a.Q + (size_t)b * a.qbs + (size_t)q * a.ldq + hh * DH;
+    const float* Kb = a.K + (size_t)b * a.kbs + hh * DH;
+    const float* Vb = a.V + (size_t)b * a.vbs + hh * DH;
     const unsigned char* kv = a.kvalid ? a.kvalid + (size_t)b * a.S : nullptr;
     unsigned long long seed = 0, step = 0;
     if (a.drop.p > 0.f) { seed = a.drop.rng_state[0]; step = a.drop.rng_state[1]; }
@@ -202,11 +203,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs 
     const int q0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
     const bool qok = q < a.T, active = q0 < a.T;
-    const float* Qp = a.Q + ((size_t)b * a.T + q) * a.ldq + hh * DH;
+    const float* Qp = a.Q + (size_t)b * a.qbs + (size_t)q * a.ldq + hh * DH;
     const float* dOp = a.dO + ((size_t)b * a.T + q) * a.lddo + hh * DH;
     const float* Op = a.O + ((size_t)b * a.T + q) * a.ldo + hh * DH;
-    const float* Kb = a.K + (size_t)b * a.S * a.ldk + hh * DH;
-    const float* Vb = a.V + (size_t)b * a.S * a.ldv + hh * DH;
+    const float* Kb = a.K + (size_t)b * a.kbs + hh * DH;
+    const float* Vb = a.V + (size_t)b * a.vbs + hh * DH;
     const unsigned char* kv = a.kvalid ? a.kvalid + (size_t)b * a.S : nullptr;
     unsigned long long seed = 0, step = 0;
     if (a.drop.p > 0.f) { seed = a.drop.rng_state[0]; step = a.drop.rng_state[1]; }
@@ -306,10 +307,10 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dkv_kernel(const AttnArgs
     const int s0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int key = s0 + l31;
     const bool active = s0 < a.S;
-    const float* Qb = a.Q + (size_t)b * a.T * a.ldq + hh * DH;
+    const float* Qb = a.Q + (size_t)b * a.qbs + hh * DH;
     const float* dOb = a.dO + (size_t)b * a.T * a.lddo + hh * DH;
-    const float* Kp = a.K + ((size_t)b * a.S + key) * a.ldk + hh * DH;
-    const float* Vp = a.V + ((size_t)b * a.S + key) * a.ldv + hh * DH;
+    const float* Kp = a.K + (size_t)b * a.kbs + (size_t)key * a.ldk + hh * DH;
+    const float* Vp = a.V + (size_t)b * a.vbs + (size_t)key * a.ldv + hh * DH;
     const bool kin = key < a.S;
     const bool kok = kin && (!a.kvalid || a.kvalid[(size_t)b * a.S + key]);
     unsigned long long seed = 0, step = 0;
@@ -418,7 +419,7 @@ bool aligned16(const void* p, int ld) { return ((reinterpret_cast<uintptr_t>(p) 
 
 extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                             int ldo, float* LSE, const unsigned char* kvalid, int B, int nh, int T, int S, int dh,
-                            const unsigned long long* rng_state, unsigned drop_site, float drop_p,
+                            int qkv_shared, const unsigned long long* rng_state, unsigned drop_site, float drop_p,
                             hipStream_t stream) {
     VQH_CHECK_ARG(B >= 0 && nh > 0 && T >= 0 && S >= 0, "vqh_attn_fwd: bad shape");
     VQH_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "vqh_attn_fwd: head dim must be 16/32/64");
@@ -429,6 +430,7 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     AttnArgs a{};
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE;
     a.kvalid = kvalid; a.B = B; a.nh = nh; a.T = T; a.S = S; a.scale = 1.0f / sqrtf((float)dh);
+    a.qbs = (qkv_shared & 1) ? 0 : (long long)T * ldq; a.kbs = (qkv_shared & 2) ? 0 : (long long)S * ldk; a.vbs = (qkv_shared & 2) ? 0 : (long long)S * ldv;
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
     // 4 waves (128 queries) share each staged K/V chunk when there are enough queries per (batch, head)
     const int NWq = (T >= 128) ? 4 : 2;
@@ -449,7 +451,7 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
 extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                             const float* O, int ldo, const float* LSE, const float* dO, int lddo, float* Dsum,
                             float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
-                            const unsigned char* kvalid, int B, int nh, int T, int S, int dh,
+                            const unsigned char* kvalid, int B, int nh, int T, int S, int dh, int qkv_shared,
                             const unsigned long long* rng_state, unsigned drop_site, float drop_p,
                             hipStream_t stream) {
     VQH_CHECK_ARG(B >= 0 && nh > 0 && T >= 0 && S >= 0, "vqh_attn_bwd: bad shape");
@@ -463,6 +465,7 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = const_cast<float*>(O); a.ldo = ldo;
     a.LSE = const_cast<float*>(LSE); a.kvalid = kvalid; a.B = B; a.nh = nh; a.T = T; a.S = S;
     a.scale = 1.0f / sqrtf((float)dh);
+    a.qbs = (qkv_shared & 1) ? 0 : (long long)T * ldq; a.kbs = (qkv_shared & 2) ? 0 : (long long)S * ldk; a.vbs = (qkv_shared & 2) ? 0 : (long long)S * ldv;
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
     a.dO = dO; a.lddo = lddo; a.Dsum = Dsum; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
     const int NWq = (T >= 128) ? 4 : 2, NWk = (S >= 128) ? 4 : 2;

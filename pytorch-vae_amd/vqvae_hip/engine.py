@@ -18,6 +18,8 @@ Memory layout in HBM (all fp32, row-major):
     attention reads heads in place from the packed QKV projection (no head transposes)
   * residual-stream gradient: one [rows, H] buffer per stack, updated in place layer by layer
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -68,6 +70,8 @@ class StepEngine:
         self.train = True
         self.ctx = None
         self.defer_ema = False
+        # first decoder / tokenizer layer: project the batch-invariant queries once instead of per sample
+        self.share_layer0 = os.environ.get("VQH_SHARE_LAYER0", "1") != "0"
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -166,30 +170,37 @@ class StepEngine:
         return out
 
     # ------------------------------------------------------------------ attention module
-    def mha_fwd(self, pre, q_in, kv_in, rows_q, rows_kv, B, T, S, nh, kvalid, p_attn, self_attn):
+    def mha_fwd(self, pre, q_in, kv_in, rows_q, rows_kv, B, T, S, nh, kvalid, p_attn, self_attn, shared=False):
+        """shared: the query-side input (and for self attention also the key/value input) is the same [T, H] block for
+        every sample (first decoder / tokenizer layer); its projection runs on T rows instead of B*T."""
         H = self.H
         W, bias = self.P[pre + ".in_proj_weight"], self.P[pre + ".in_proj_bias"]
+        pq = T if shared else rows_q
         if self_attn:
-            qkv = self.T(pre + ".qkv", rows_q, 3 * H)
-            self.lin_fwd(q_in, H, rows_q, W, bias, qkv, 3 * H)
+            qkv = self.T(pre + ".qkv", pq, 3 * H)
+            self.lin_fwd(q_in, H, pq, W, bias, qkv, 3 * H)
             q, k, v, ldq, ldk = qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H
         else:
-            qp = self.T(pre + ".q", rows_q, H)
+            qp = self.T(pre + ".q", pq, H)
             kvp = self.T(pre + ".kv", rows_kv, 2 * H)
-            self.lin_fwd(q_in, H, rows_q, W[:H], bias[:H], qp, H)
+            self.lin_fwd(q_in, H, pq, W[:H], bias[:H], qp, H)
             self.lin_fwd(kv_in, H, rows_kv, W[H:], bias[H:], kvp, 2 * H)
             q, k, v, ldq, ldk = qp, kvp, kvp[:, H:], H, 2 * H
         ao = self.T(pre + ".ao", rows_q, H)
         lse = self.T(pre + ".lse", B * nh * T)
-        call("vqh_attn_fwd", q, ldq, k, ldk, v, ldk, ao, H, lse, kvalid, B, nh, T, S, H // nh, self.rng,
+        flag = (3 if self_attn else 1) if shared else 0
+        call("vqh_attn_fwd", q, ldq, k, ldk, v, ldk, ao, H, lse, kvalid, B, nh, T, S, H // nh, flag, self.rng,
              self.site(pre + ".attn_drop"), p_attn)
         return ao
 
     def mha_bwd(self, pre, d_ao, q_in, kv_in, rows_q, rows_kv, B, T, S, nh, kvalid, p_attn, self_attn,
-                d_q_in, d_kv_in, kv_beta):
+                d_q_in, d_kv_in, kv_beta, shared=False):
         """d_ao: grad of the head-concatenated attention output (before out_proj).
-        Writes d_q_in (beta 0) and, for cross attention, d_kv_in (beta kv_beta)."""
+        Writes d_q_in (beta 0) and, for cross attention, d_kv_in (beta kv_beta).
+        shared (see mha_fwd): the projection's weight and input gradients are linear in dQ(KV), so they are taken from
+        its sum over the batch: d_q_in is then [T, H] = the batch-summed input gradient."""
         H = self.H
+        flag = (3 if self_attn else 1) if shared else 0
         W = self.P[pre + ".in_proj_weight"]
         gW, gb = self.G[pre + ".in_proj_weight"], self.G[pre + ".in_proj_bias"]
         ao, lse = self.buf[pre + ".ao"], self.buf[pre + ".lse"]
@@ -199,7 +210,11 @@ class StepEngine:
             qkv = self.buf[pre + ".qkv"]
             dqkv = self.T("tmp.dqkv", rows_q, 3 * H)
             call("vqh_attn_bwd", qkv, 3 * H, qkv[:, H:], 3 * H, qkv[:, 2 * H:], 3 * H, ao, H, lse, d_ao, H, dsum,
-                 dqkv, 3 * H, dqkv[:, H:], 3 * H, dqkv[:, 2 * H:], 3 * H, kvalid, B, nh, T, S, H // nh, self.rng, site, p_attn)
+                 dqkv, 3 * H, dqkv[:, H:], 3 * H, dqkv[:, 2 * H:], 3 * H, kvalid, B, nh, T, S, H // nh, flag, self.rng, site, p_attn)
+            if shared:
+                dsh = self.T("tmp.dqkv_sh", T, 3 * H)
+                call("vqh_colsum", dqkv, T * 3 * H, B, T * 3 * H, dsh, 0.0, self.ws, self.ws.numel())
+                dqkv, rows_q = dsh, T
             self.lin_wgrad(dqkv, 3 * H, q_in, H, rows_q, gW, gb)
             self.lin_dgrad(dqkv, 3 * H, rows_q, W, d_q_in, H)
         else:
@@ -207,29 +222,38 @@ class StepEngine:
             dq = self.T("tmp.dq", rows_q, H)
             dkv = self.T("tmp.dkv", rows_kv, 2 * H)
             call("vqh_attn_bwd", qp, H, kvp, 2 * H, kvp[:, H:], 2 * H, ao, H, lse, d_ao, H, dsum,
-                 dq, H, dkv, 2 * H, dkv[:, H:], 2 * H, kvalid, B, nh, T, S, H // nh, self.rng, site, p_attn)
+                 dq, H, dkv, 2 * H, dkv[:, H:], 2 * H, kvalid, B, nh, T, S, H // nh, flag, self.rng, site, p_attn)
+            if shared:
+                dsh = self.T("tmp.dq_sh", T, H)
+                call("vqh_colsum", dq, T * H, B, T * H, dsh, 0.0, self.ws, self.ws.numel())
+                dq, rows_q = dsh, T
             self.lin_wgrad(dq, H, q_in, H, rows_q, gW[:H], gb[:H])
             self.lin_wgrad(dkv, 2 * H, kv_in, H, rows_kv, gW[H:], gb[H:])
             self.lin_dgrad(dq, H, rows_q, W[:H], d_q_in, H)
             self.lin_dgrad(dkv, 2 * H, rows_kv, W[H:], d_kv_in, H, beta=kv_beta)
 
     # ------------------------------------------------------------------ transformer blocks
-    def attn_block_fwd(self, pre, attn, norm, x0, rows, B, T, nh, kvalid, mem=None, rows_kv=None, S=None, p=0.1):
-        """x1 = x0 + dropout(out_proj(MHA(LN(x0) [, mem])))"""
+    def attn_block_fwd(self, pre, attn, norm, x0, rows, B, T, nh, kvalid, mem=None, rows_kv=None, S=None, p=0.1,
+                       shared=False):
+        """x1 = x0 + dropout(out_proj(MHA(LN(x0) [, mem])));  shared: x0 repeats one [T, H] block per sample."""
         H = self.H
-        h = self.T(f"{pre}.{norm}.y", rows, H)
-        self.ln_fwd(f"{pre}.{norm}", x0, H, h, H, rows, f"{pre}.{norm}")
+        nr = T if shared else rows
+        h = self.T(f"{pre}.{norm}.y", nr, H)
+        self.ln_fwd(f"{pre}.{norm}", x0, H, h, H, nr, f"{pre}.{norm}")
         self_attn = mem is None
         ao = self.mha_fwd(f"{pre}.{attn}", h, h if self_attn else mem, rows, rows if self_attn else rows_kv, B, T,
-                          T if self_attn else S, nh, kvalid, self.pdrop(p), self_attn)
+                          T if self_attn else S, nh, kvalid, self.pdrop(p), self_attn, shared=shared)
         x1 = self.T(f"{pre}.{attn}.out", rows, H)
         self.lin_fwd(ao, H, rows, self.P[f"{pre}.{attn}.out_proj.weight"], self.P[f"{pre}.{attn}.out_proj.bias"], x1, H,
                      mode=L.EPI_DROP_RESID, aux_in=x0, ldaux=H, site=self.site(f"{pre}.{attn}.drop"), p=self.pdrop(p))
         return x1
 
     def attn_block_bwd(self, pre, attn, norm, x0, dres, rows, B, T, nh, kvalid, mem=None, rows_kv=None, S=None,
-                       d_mem=None, mem_beta=0.0, p=0.1):
-        """dres holds d x1 on entry and d x0 on exit (in place)."""
+                       d_mem=None, mem_beta=0.0, p=0.1, shared=False):
+        """dres holds d x1 on entry and d x0 on exit (in place).
+        shared: dres keeps only the residual branch; the LayerNorm branch's gradient, already summed over the batch
+        (LayerNorm backward is linear in dy for fixed x), is returned as a [T, H] buffer for the caller to add to the
+        gradient of the broadcast parameter."""
         H = self.H
         a = f"{pre}.{attn}"
         self_attn = mem is None
@@ -240,8 +264,13 @@ class StepEngine:
         self.lin_dgrad(dy, H, rows, self.P[a + ".out_proj.weight"], d_ao, H)
         dh = self.T("tmp.dh", rows, H)
         self.mha_bwd(a, d_ao, h, h if self_attn else mem, rows, rows if self_attn else rows_kv, B, T,
-                     T if self_attn else S, nh, kvalid, self.pdrop(p), self_attn, dh, d_mem, mem_beta)
+                     T if self_attn else S, nh, kvalid, self.pdrop(p), self_attn, dh, d_mem, mem_beta, shared=shared)
+        if shared:
+            dx_sh = self.T(f"{pre}.{norm}.dx_sh", T, H)
+            self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dx_sh, H, False, T)
+            return dx_sh
         self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dres, H, True, rows)
+        return None
 
     def ffn_block_fwd(self, pre, norm, lin1, lin2, x0, rows, act, p_inner, p_out):
         """x1 = x0 + dropout(lin2(dropout(act(lin1(LN(x0))))))   act: 'relu' (encoder/decoder) or 'gelu' (tokenizer)"""
@@ -372,10 +401,12 @@ class StepEngine:
         qs = [q]
         for i in range(self.m.tokenizer_layers):
             pre = f"tokenizer.layers.{i}"
-            qn, kvn = self.T(pre + ".ln_q.y", MN, H), self.T(pre + ".ln_kv.y", ML, H)
-            self.ln_fwd(pre + ".ln_q", q, H, qn, H, MN, pre + ".ln_q")
+            sh = self.share_layer0 and i == 0          # every sample starts from the same learned queries
+            nq = N if sh else MN
+            qn, kvn = self.T(pre + ".ln_q.y", nq, H), self.T(pre + ".ln_kv.y", ML, H)
+            self.ln_fwd(pre + ".ln_q", q, H, qn, H, nq, pre + ".ln_q")
             self.ln_fwd(pre + ".ln_kv", hf, H, kvn, H, ML, pre + ".ln_kv")
-            ao = self.mha_fwd(pre + ".attn", qn, kvn, MN, ML, B, N, Lq, self.tnh, mask, self.pdrop(pd), False)
+            ao = self.mha_fwd(pre + ".attn", qn, kvn, MN, ML, B, N, Lq, self.tnh, mask, self.pdrop(pd), False, shared=sh)
             q1 = self.T(pre + ".attn.out", MN, H)
             self.lin_fwd(ao, H, MN, self.P[pre + ".attn.out_proj.weight"], self.P[pre + ".attn.out_proj.bias"], q1, H,
                          mode=L.EPI_DROP_RESID, aux_in=q, ldaux=H, site=self.site(pre + ".drop"), p=self.pdrop(pd))
@@ -413,11 +444,19 @@ class StepEngine:
             d_ao = self.T("tmp.dao_tok", MN, H)
             self.lin_dgrad(dy, H, MN, self.P[a + ".out_proj.weight"], d_ao, H)
             dqn, dkvn = self.T("tmp.dqn", MN, H), self.T("tmp.dkvn", ML, H)
+            sh = self.share_layer0 and i == 0
             self.mha_bwd(a, d_ao, self.buf[pre + ".ln_q.y"], self.buf[pre + ".ln_kv.y"], MN, ML, B, N, Lq, self.tnh, mask,
-                         self.pdrop(pd), False, dqn, dkvn, 0.0)
-            self.ln_bwd(pre + ".ln_q", dqn, H, qs[2 * i], H, pre + ".ln_q", dres, H, True, MN)
+                         self.pdrop(pd), False, dqn, dkvn, 0.0, shared=sh)
+            if sh:      # dqn[:N] is the batch-summed gradient; the LayerNorm branch goes straight to the parameter grad
+                dq_sh = self.T("tmp.dq0_sh", N, H)
+                self.ln_bwd(pre + ".ln_q", dqn, H, qs[0], H, pre + ".ln_q", dq_sh, H, False, N)
+            else:
+                self.ln_bwd(pre + ".ln_q", dqn, H, qs[2 * i], H, pre + ".ln_q", dres, H, True, MN)
             self.ln_bwd(pre + ".ln_kv", dkvn, H, self.buf["fuse.out"], H, pre + ".ln_kv", d_hf, H, i != nl - 1, ML)
-        call("vqh_colsum", dres, N * H, B, N * H, self.G["tokenizer.queries"], 0.0, self.ws, self.ws.numel())
+        gq = self.G["tokenizer.queries"]
+        call("vqh_colsum", dres, N * H, B, N * H, gq, 0.0, self.ws, self.ws.numel())
+        if self.share_layer0 and nl > 0:
+            call("vqh_add", gq, dq_sh, gq, N * H)
         return d_hf
 
     def _soft_vq_params(self):
@@ -561,7 +600,8 @@ class StepEngine:
         xs = [t]
         for i in range(self.m.num_layers):
             pre = f"decoder.layers.{i}"
-            t = self.attn_block_fwd(pre, "self_attn", "norm1", t, ML, B, Lq, self.nh, mask)
+            t = self.attn_block_fwd(pre, "self_attn", "norm1", t, ML, B, Lq, self.nh, mask,
+                                    shared=self.share_layer0 and i == 0)
             xs.append(t)
             t = self.attn_block_fwd(pre, "multihead_attn", "norm2", t, ML, B, Lq, self.nh, None, mem=mem, rows_kv=MN, S=Nmem)
             xs.append(t)
@@ -593,11 +633,14 @@ class StepEngine:
             self.ffn_block_bwd(pre, "norm3", "linear1", "linear2", xs[3 * i + 2], dres, ML, "relu", 0.1, 0.1)
             self.attn_block_bwd(pre, "multihead_attn", "norm2", xs[3 * i + 1], dres, ML, B, Lq, self.nh, None, mem=mem,
                                 rows_kv=MN, S=Nmem, d_mem=d_mem, mem_beta=0.0 if i == nl - 1 else 1.0)
-            self.attn_block_bwd(pre, "self_attn", "norm1", xs[3 * i], dres, ML, B, Lq, self.nh, mask)
+            dx_sh = self.attn_block_bwd(pre, "self_attn", "norm1", xs[3 * i], dres, ML, B, Lq, self.nh, mask,
+                                        shared=self.share_layer0 and i == 0)
         # tgt = query_embed[:L] + pos_enc[:L] broadcast over the batch
         gq = self.G["query_embed.weight"]
         call("vqh_memset", gq, 0, gq.numel() * 4)
         call("vqh_colsum", dres, Lq * H, B, Lq * H, gq, 0.0, self.ws, self.ws.numel())
+        if dx_sh is not None:
+            call("vqh_add", gq, dx_sh, gq, Lq * H)
         dmemf = self.T("tmp.dmemf", MN, H)
         self.ln_bwd("mem_ln", d_mem, H, self.buf["dec.memf"], H, "mem_ln", dmemf, H, False, MN)
         self.lin_wgrad(dmemf, H, c["dec_z"], D, MN, self.G["from_code.weight"], self.G["from_code.bias"])

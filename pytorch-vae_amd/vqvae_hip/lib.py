@@ -40,8 +40,8 @@ _PROTOS = {
     "vqh_softmax_bwd_colgrad": "pipiip",
     "vqh_usage_entropy_finish": "piifppiip",
     "vqh_vq_mix": "pppfplp",
-    "vqh_attn_fwd": "pipipipippiiiiipufp",
-    "vqh_attn_bwd": "pipipipippippipipipiiiiipufp",
+    "vqh_attn_fwd": "pipipipippiiiiiipufp",
+    "vqh_attn_bwd": "pipipipippippipipipiiiiiipufp",
     "vqh_vq_nearest": "pipipiiiifplp",
     "vqh_vq_gather": "pipipippiip",
     "vqh_vq_finish": "pipippiip",

@@ -25,9 +25,9 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 for p, m in ((0.0, None), (0.0, mask), (0.1, mask)):
-    f = lambda: L.call("vqh_attn_fwd", q, 3 * E, k, 3 * E, v, 3 * E, o, E, lse, m, B, nh, T, S, dh, rng, 1, p)
+    f = lambda: L.call("vqh_attn_fwd", q, 3 * E, k, 3 * E, v, 3 * E, o, E, lse, m, B, nh, T, S, dh, 0, rng, 1, p)
     b = lambda: L.call("vqh_attn_bwd", q, 3 * E, k, 3 * E, v, 3 * E, o, E, lse, do, E, dsum, dqkv, 3 * E, dqkv[:, E:], 3 * E,
-                       dqkv[:, 2 * E:], 3 * E, m, B, nh, T, S, dh, rng, 1, p)
+                       dqkv[:, 2 * E:], 3 * E, m, B, nh, T, S, dh, 0, rng, 1, p)
     flops = 4.0 * B * nh * T * S * dh
     tf, tb = t(f), t(b)
     print(f"p={p} mask={'yes' if m is not None else 'no'}: fwd {tf:7.1f} us ({flops/tf/1e6:5.1f} TF)  bwd(dq+dkv) {tb:7.1f} us ({2.5*flops/tb/1e6:5.1f} TF)", flush=True)

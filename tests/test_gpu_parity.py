@@ -128,7 +128,7 @@ def test_attention_forward_backward(B, nh, T, S, dh, self_attn, ragged):
         lens = torch.randint(max(1, S // 2), S + 1, (B,))
         valid = (torch.arange(S)[None] < lens[:, None]).to(DEV)
     o, lse = torch.empty(B, T, E, device=DEV), torch.empty(B * nh * T, device=DEV)
-    L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, valid, B, nh, T, S, dh, None, 0, 0.0)
+    L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, valid, B, nh, T, S, dh, 0, None, 0, 0.0)
     qd, kd, vd = (t.double().cpu().requires_grad_(True) for t in (q, k, v))
     sc = (qd.view(B, T, nh, dh).transpose(1, 2) @ kd.view(B, S, nh, dh).transpose(1, 2).transpose(-1, -2)) / math.sqrt(dh)
     sc = sc.masked_fill(~valid.cpu()[:, None, None, :], float("-inf"))
@@ -137,7 +137,7 @@ def test_attention_forward_backward(B, nh, T, S, dh, self_attn, ragged):
     assert rel(o, ref) < 3e-6
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     dsum = torch.empty(B * nh * T, device=DEV)
-    L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, valid, B, nh, T, S, dh, None, 0, 0.0)
+    L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, valid, B, nh, T, S, dh, 0, None, 0, 0.0)
     assert rel(dq, qd.grad) < 5e-6 and rel(dk, kd.grad) < 5e-6 and rel(dv, vd.grad) < 5e-6
 
 
@@ -151,13 +151,13 @@ def test_attention_dropout_consistent_between_forward_and_backward():
     q, k, v, do = (torch.randn(B, T, E, device=DEV) for _ in range(4))
     rng = torch.tensor([99, 3], device=DEV, dtype=torch.int64)
     o, lse = torch.empty(B, T, E, device=DEV), torch.empty(B * nh * T, device=DEV)
-    L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, None, B, nh, T, S, dh, rng, 11, 0.25)
+    L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, None, B, nh, T, S, dh, 0, rng, 11, 0.25)
     dq, dk, dv, dsum = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty(B * nh * T, device=DEV)
-    L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, None, B, nh, T, S, dh, rng, 11, 0.25)
+    L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, None, B, nh, T, S, dh, 0, rng, 11, 0.25)
     lhs, rhs = float((o.double() * do.double()).sum()), float((v.double() * dv.double()).sum())
     assert abs(lhs - rhs) < 1e-4 * abs(lhs)
     o2 = torch.empty_like(o)
-    L.call("vqh_attn_fwd", q, E, k, E, v, E, o2, E, lse, None, B, nh, T, S, dh, None, 0, 0.0)
+    L.call("vqh_attn_fwd", q, E, k, E, v, E, o2, E, lse, None, B, nh, T, S, dh, 0, None, 0, 0.0)
     assert float((o - o2).abs().max()) > 1e-3          # dropout really changed the output
 
 
@@ -172,15 +172,15 @@ def test_attention_dropout_gradients_match_autograd_with_extracted_mask():
     rng = torch.tensor([7, 5], device=DEV, dtype=torch.int64)
     eye = torch.eye(S, dh, device=DEV).repeat(1, nh)[None].repeat(B, 1, 1).contiguous()      # V[b, s, head*dh + d] = (s == d)
     o, o0, lse = torch.empty(B, T, E, device=DEV), torch.empty(B, T, E, device=DEV), torch.empty(B * nh * T, device=DEV)
-    L.call("vqh_attn_fwd", q, E, k, E, eye, E, o, E, lse, None, B, nh, T, S, dh, rng, 3, p)
-    L.call("vqh_attn_fwd", q, E, k, E, eye, E, o0, E, lse, None, B, nh, T, S, dh, None, 0, 0.0)
+    L.call("vqh_attn_fwd", q, E, k, E, eye, E, o, E, lse, None, B, nh, T, S, dh, 0, rng, 3, p)
+    L.call("vqh_attn_fwd", q, E, k, E, eye, E, o0, E, lse, None, B, nh, T, S, dh, 0, None, 0, 0.0)
     keep = (o / o0).view(B, T, nh, dh).transpose(1, 2)[..., :S]                                # [B, nh, T, S] in {0, 1/(1-p)}
     assert abs(float((keep == 0).float().mean()) - p) < 0.05
     assert float(((keep - 1 / (1 - p)).abs() < 1e-4).float().mean() + (keep == 0).float().mean()) > 0.999
     v = torch.randn(B, S, E, device=DEV)
-    L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, None, B, nh, T, S, dh, rng, 3, p)
+    L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, None, B, nh, T, S, dh, 0, rng, 3, p)
     dq, dk, dv, dsum = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty(B * nh * T, device=DEV)
-    L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, None, B, nh, T, S, dh, rng, 3, p)
+    L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, None, B, nh, T, S, dh, 0, rng, 3, p)
     qd, kd, vd = (t.double().cpu().requires_grad_(True) for t in (q, k, v))
     sc = (qd.view(B, T, nh, dh).transpose(1, 2) @ kd.view(B, S, nh, dh).transpose(1, 2).transpose(-1, -2)) / math.sqrt(dh)
     pm = torch.softmax(sc, -1) * keep.double().cpu().round(decimals=6)
@@ -320,6 +320,26 @@ def test_train_step_matches_reference_golden(name, cfg_kw, _r):
     if m.use_vq:
         assert rel(m.quantizer.embedding, g["q_emb_0"]) < 1e-5
         assert rel(m.quantizer.ema_cluster_size, g["q_ecs_0"]) < 1e-6
+
+
+def test_layer0_shared_projection_equals_per_sample_path():
+    """The first decoder / tokenizer layer projects its batch-invariant queries once (engine.share_layer0); the
+    per-sample path (what the reference computes) must give the same losses and gradients."""
+    name, cfg_kw, _r = MODEL_CASES[0]
+    g = load_golden(name)
+    batches, sd0, weights = model_inputs(g, cfg_kw)
+    res = []
+    for share in (True, False):
+        m, eng = _model(cfg_kw, sd0)
+        eng.share_layer0 = share
+        m.train()
+        x, mask = batches[0]
+        ld = m.loss_function(*m(x.to(DEV), mask.to(DEV)), **weights)
+        m.backward()
+        torch.cuda.synchronize()
+        res.append((float(ld["loss"]), eng.flat_g.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    assert rel(res[0][1], res[1][1]) < 1e-4
 
 
 @pytest.mark.parametrize("name,cfg_kw,_r", MODEL_CASES)
