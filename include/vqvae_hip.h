@@ -12,7 +12,7 @@
  *     allocation, no ownership transfer: the caller owns every buffer including `workspace`
  *   - returns 0 on success, <0 on error; vqh_last_error() returns a thread-local message
  *   - safe to capture into a hipGraph (all step-varying scalars are read from device memory)
- *   - dropout masks are Philox4x32-10 functions of (seed, step, site, element): rng_state points to
+ *   - dropout masks are counter-hash functions of (seed, step, site, element): rng_state points to
  *     two device uint64 {seed, step}; backward regenerates the forward mask from the same site id
  */
 #ifndef VQVAE_HIP_H

@@ -45,15 +45,10 @@ struct AttnArgs {
 };
 
 // ---- attention dropout stream ----------------------------------------------------------------------
-// Attention probabilities are dropped with a counter hash instead of Philox: element (row = (b*nh+head)*T + q, key)
-// keeps iff mix32(rowkey(row) ^ key*GOLDEN) * 2^-32 >= p, with rowkey = mix32 chain over (seed, step, site, row).
-// mix32 is the 2-multiply "lowbias32" avalanche hash: ~10 VALU ops per element (Philox4x32-10 cost ~150 per call and
-// made the softmax phase as long as the tile's MFMA time).  Any kernel can evaluate any (row, key) directly, so the
-// forward, dQ and dK/dV kernels regenerate identical masks whatever their register layout.
-__device__ __forceinline__ unsigned mix32(unsigned x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
+// Attention probabilities use the counter hash of common.h keyed per row: element (row = (b*nh+head)*T + q, key)
+// keeps iff mix32(rowkey(row) ^ key*GOLDEN) * 2^-32 >= p, with rowkey = mix32 chain over (seed, step, site, row):
+// ~10 VALU ops per element.  Any kernel can evaluate any (row, key) directly, so the forward, dQ and dK/dV kernels
+// regenerate identical masks whatever their register layout.
 __device__ __forceinline__ unsigned attn_rowkey(const DropCfg& d, unsigned long long seed, unsigned long long step,
                                                 unsigned long long row) {
     unsigned k = mix32((unsigned)seed ^ (d.site * 0x9E3779B9U));

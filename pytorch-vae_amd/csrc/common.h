@@ -32,22 +32,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 counter RNG: the dropout mask of element e at dropout site s in training step t is
-// a pure function of (seed, t, s, e), so backward regenerates it instead of storing a mask.
-// rng_state (device memory): [0] = seed, [1] = step counter (advanced once per step by a kernel,
-// so a captured hipGraph replays with fresh masks).
+// Dropout stream: the keep/drop decision of element e at dropout site s in training step t is a pure function of
+// (seed, t, s, e), so backward regenerates it instead of storing a mask.  rng_state (device memory): [0] = seed,
+// [1] = step counter (advanced once per step by a kernel, so a captured hipGraph replays with fresh masks).
+// The function is a counter hash: key = mix32 chain over (seed, step, site), element e keeps iff
+// mix32(key ^ e * GOLDEN) * 2^-32 >= p, with mix32 the 2-multiply "lowbias32" avalanche finaliser -- about 10 VALU
+// ops per element.  (Philox4x32-10, used at first, costs ~100 ops per 4 elements and showed up as +4 % on the FFN
+// GEMMs whose epilogue draws 64 decisions per lane.)  The attention kernels use the same construction keyed per
+// (row, key) -- attention.hip.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-        uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += W0;
-        key.y += W1;
-    }
-    return ctr;
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
 }
 
 struct DropCfg {
@@ -57,25 +53,25 @@ struct DropCfg {
     float scale;                          // 1/(1-p)
 };
 
-// keep-factor (0 or 1/(1-p)) for 4 consecutive elements starting at element index 4*quad.
-__device__ __forceinline__ void drop4(const DropCfg& d, unsigned long long seed, unsigned long long step,
-                                      unsigned long long quad, float out[4]) {
-    uint4 c = make_uint4((uint32_t)quad, (uint32_t)(quad >> 32), d.site, (uint32_t)step);
-    uint2 k = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
-    uint4 r = philox4x32_10(c, k);
-    const float inv = 2.3283064365386963e-10f;  // 2^-32
-    out[0] = (r.x * inv >= d.p) ? d.scale : 0.f;
-    out[1] = (r.y * inv >= d.p) ? d.scale : 0.f;
-    out[2] = (r.z * inv >= d.p) ? d.scale : 0.f;
-    out[3] = (r.w * inv >= d.p) ? d.scale : 0.f;
+// per-(seed, step, site) key: compute once per thread, then drop_keep per element
+__device__ __forceinline__ unsigned drop_key(const DropCfg& d, unsigned long long seed, unsigned long long step) {
+    unsigned k = mix32((unsigned)seed ^ (d.site * 0x9E3779B9U));
+    k = mix32(k ^ (unsigned)(seed >> 32) ^ ((unsigned)step * 0x85EBCA6BU));
+    return mix32(k ^ (unsigned)(step >> 32) ^ 0x5bd1e995U);
 }
 
-// keep-factor of one element (elem = linear element index inside the dropout site's tensor)
-__device__ __forceinline__ float drop1(const DropCfg& d, unsigned long long seed, unsigned long long step,
-                                       unsigned long long elem) {
-    float f[4];
-    drop4(d, seed, step, elem >> 2, f);
-    return f[elem & 3];
+// keep-factor (0 or 1/(1-p)) of one element (elem = linear element index inside the dropout site's tensor)
+__device__ __forceinline__ float drop_keep(const DropCfg& d, unsigned key, unsigned long long elem) {
+    const unsigned hi = (unsigned)(elem >> 32);
+    if (hi) key = mix32(key ^ hi);
+    const unsigned r = mix32(key ^ ((unsigned)elem * 0x9E3779B9U));
+    return (r * 2.3283064365386963e-10f >= d.p) ? d.scale : 0.f;
+}
+
+// keep-factors of the 4 consecutive elements 4*quad .. 4*quad+3
+__device__ __forceinline__ void drop4(const DropCfg& d, unsigned key, unsigned long long quad, float out[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = drop_keep(d, key, quad * 4 + e);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

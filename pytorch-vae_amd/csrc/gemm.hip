@@ -66,22 +66,21 @@ struct GemmArgs {
                            // 2 = skip epilogue stores (timing only), 4 = skip global loads after the first tile (timing only)
 };
 
-__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float acc, int row, int col,
-                                                unsigned long long seed, unsigned long long step) {
+__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float acc, int row, int col, unsigned dkey) {
     float v = acc;
     if (g.mode <= EPI_SIGMOID) {
         if (g.bias) v += g.bias[col];
         switch (g.mode) {
             case EPI_RELU_DROP:
                 v = fmaxf(v, 0.f);
-                if (g.drop.p > 0.f) v *= drop1(g.drop, seed, step, (unsigned long long)row * g.N + col);
+                if (g.drop.p > 0.f) v *= drop_keep(g.drop, dkey, (unsigned long long)row * g.N + col);
                 break;
             case EPI_GELU:
                 g.aux_out[(size_t)row * g.ldaux + col] = v;
                 v = gelu_erf(v);
                 break;
             case EPI_DROP_RESID:
-                if (g.drop.p > 0.f) v *= drop1(g.drop, seed, step, (unsigned long long)row * g.N + col);
+                if (g.drop.p > 0.f) v *= drop_keep(g.drop, dkey, (unsigned long long)row * g.N + col);
                 v += g.aux_in[(size_t)row * g.ldaux + col];
                 break;
             case EPI_SIGMOID:
@@ -190,8 +189,12 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int ro
     }
 }
 
-template <bool A_KC, bool B_KC, int BKT>
+// MODE >= 0: epilogue specialised at compile time (small enough to unroll fully, which the aux prefetch needs: its 16
+// registers are indexed by the unrolled loop counters); MODE < 0: generic kernel, epilogue selected by g.mode at run
+// time and unrolled 4x (a fully unrolled generic epilogue cost every GEMM ~9 %: 292 -> 320 us on 16384x2048x512).
+template <bool A_KC, bool B_KC, int BKT, int MODE>
 __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const GemmArgs g) {
+    const int mode = (MODE >= 0) ? MODE : g.mode;
     constexpr int A_TILE = Tile<BKT>::A_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // stage s: A tile at smem + 2*s*A_TILE, B tile right behind it
@@ -248,10 +251,23 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     }
     __syncthreads();
 
+    // The epilogue's second input (residual stream / saved activation: 64 floats per lane, laid out as the epilogue
+    // reads them) is fetched two K-steps before the end so its HBM latency hides under the last MFMAs instead of
+    // stalling the epilogue (+15 % on the FFN dgrad, +8 % on K=512 out-projections when loaded in place).
+    const bool pre_aux = (MODE == EPI_DROP_RESID || MODE > EPI_SIGMOID) && g.aux_in && !g.ws && g.vecC && nk > 0 &&
+                         (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.flags & 16);
+    const int kpre = nk >= 2 ? nk - 2 : 0;
+    f32x4 auxr[16];
+
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nk);
         if (more && !(g.flags & 4)) LOAD_AB(kbeg + (kt + 1) * BKT)
+        if (pre_aux && kt == kpre) {
+            const float* ap = g.aux_in + (size_t)(m0 + wm * 64 + (lane >> 4)) * g.ldaux + n0 + wn * 64 + (lane & 15) * 4;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) auxr[q] = *reinterpret_cast<const f32x4*>(ap + (size_t)(q * 4) * g.ldaux);
+        }
         const float* a_s = AS(cur);
         const float* b_s = BS(cur);
 #pragma unroll
@@ -290,11 +306,8 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     // 4-byte accesses 128 B apart.  Stage the wave's 64x64 result through its (now idle) share of the LDS
     // and let each lane handle 4 consecutive columns: 16-byte global stores / aux loads, 16 per lane
     // instead of 64 (the scattered form ran at ~1 TB/s and cost ~30 % of a K=512 GEMM).
-    unsigned long long seed = 0, step = 0;
-    if (g.drop.p > 0.f && g.drop.rng_state) {
-        seed = g.drop.rng_state[0];
-        step = g.drop.rng_state[1];
-    }
+    unsigned dkey = 0;
+    if (g.drop.p > 0.f && g.drop.rng_state) dkey = drop_key(g.drop, g.drop.rng_state[0], g.drop.rng_state[1]);
     if (g.flags & 2) {
         float s = 0.f;
 #pragma unroll
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
             ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[half][j][r];
     __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
+#pragma unroll(MODE >= 0 ? 8 : 4)
     for (int it = 0; it < 8; ++it) {
         const int rl = it * 4 + (lane >> 4);
         const int row = m0 + wm * 64 + half * 32 + rl;
@@ -339,28 +352,29 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
         float* cptr = g.C + (size_t)row * g.ldc + col;
         if (full) {
             // ---- vector path: 4 consecutive columns
-            if (g.mode <= EPI_SIGMOID) {
+            if (mode <= EPI_SIGMOID) {
                 if (g.bias) { const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col); v += bb; }
-                if (g.mode == EPI_RELU_DROP || g.mode == EPI_DROP_RESID) {
-                    if (g.mode == EPI_RELU_DROP)
+                if (mode == EPI_RELU_DROP || mode == EPI_DROP_RESID) {
+                    if (mode == EPI_RELU_DROP)
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     if (g.drop.p > 0.f) {
                         float f[4];
-                        drop4(g.drop, seed, step, ((unsigned long long)row * g.N + col) >> 2, f);
+                        drop4(g.drop, dkey, ((unsigned long long)row * g.N + col) >> 2, f);
                         for (int e = 0; e < 4; ++e) v[e] *= f[e];
                     }
-                    if (g.mode == EPI_DROP_RESID) v += *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
-                } else if (g.mode == EPI_GELU) {
+                    if (mode == EPI_DROP_RESID)
+                        v += pre_aux ? auxr[half * 8 + it] : *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
+                } else if (mode == EPI_GELU) {
                     *reinterpret_cast<f32x4*>(g.aux_out + (size_t)row * g.ldaux + col) = v;
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                } else if (g.mode == EPI_SIGMOID) {
+                } else if (mode == EPI_SIGMOID) {
                     for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
                 }
             } else {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
-                if (g.mode == EPI_MUL_POSMASK)
+                const f32x4 a = pre_aux ? auxr[half * 8 + it] : *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
+                if (mode == EPI_MUL_POSMASK)
                     for (int e = 0; e < 4; ++e) v[e] = (a[e] > 0.f) ? v[e] * g.drop.scale : 0.f;
-                else if (g.mode == EPI_MUL_GELUGRAD)
+                else if (mode == EPI_MUL_GELUGRAD)
                     for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
                 else
                     for (int e = 0; e < 4; ++e) v[e] *= a[e] * (1.f - a[e]);
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
         } else {
             for (int e = 0; e < 4; ++e) {
                 if (col + e >= g.N) break;
-                float x = epilogue_value(g, v[e], row, col + e, seed, step);
+                float x = epilogue_value(g, v[e], row, col + e, dkey);
                 if (g.beta != 0.f) x += g.beta * cptr[e];
                 cptr[e] = x;
             }
@@ -404,12 +418,12 @@ __global__ void splitk_reduce(const float* __restrict__ ws, int S, int M, int N,
     }
 }
 
-template <bool A_KC, bool B_KC, int BKT>
+template <bool A_KC, bool B_KC, int BKT, int MODE = -1>
 int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     static bool attr_set = false;
     const size_t smem = (size_t)4 * Tile<BKT>::A_TILE * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<A_KC, B_KC, BKT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma<A_KC, B_KC, BKT, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             vqh_set_error(hipGetErrorString(e));
@@ -419,7 +433,7 @@ int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles, 1, splits);
-    hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC, BKT>), grid, dim3(256), smem, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC, BKT, MODE>), grid, dim3(256), smem, stream, g);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
@@ -492,6 +506,14 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
         else if (a_kcontig && !b_kcontig) rc = launch<true, false, 16>(g, splits, stream);
         else if (!a_kcontig && b_kcontig) rc = launch<false, true, 16>(g, splits, stream);
         else rc = launch<false, false, 16>(g, splits, stream);
+    } else if (splits == 1 && g.vecC && a_kcontig && b_kcontig && mode == EPI_DROP_RESID) {
+        rc = launch<true, true, 32, EPI_DROP_RESID>(g, splits, stream);       // out-projections / FFN2 (forward)
+    } else if (splits == 1 && g.vecC && a_kcontig && b_kcontig && mode == EPI_RELU_DROP) {
+        rc = launch<true, true, 32, EPI_RELU_DROP>(g, splits, stream);        // FFN1 (forward)
+    } else if (splits == 1 && g.vecC && a_kcontig && !b_kcontig && mode == EPI_MUL_POSMASK) {
+        rc = launch<true, false, 32, EPI_MUL_POSMASK>(g, splits, stream);     // FFN1 input gradient
+    } else if (splits == 1 && g.vecC && a_kcontig && !b_kcontig && mode == EPI_MUL_GELUGRAD) {
+        rc = launch<true, false, 32, EPI_MUL_GELUGRAD>(g, splits, stream);    // tokenizer FFN / fuse MLP input gradient
     } else {
         if (a_kcontig && b_kcontig) rc = launch<true, true, 32>(g, splits, stream);
         else if (a_kcontig && !b_kcontig) rc = launch<true, false, 32>(g, splits, stream);

@@ -266,17 +266,14 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ W, const float* __restrict__ b,
                                                         const float* __restrict__ pe, float* __restrict__ out,
                                                         int rows, int L, int H, DropCfg drop) {
-    unsigned long long seed = 0, step = 0;
-    if (drop.p > 0.f) {
-        seed = drop.rng_state[0];
-        step = drop.rng_state[1];
-    }
+    unsigned dkey = 0;
+    if (drop.p > 0.f) dkey = drop_key(drop, drop.rng_state[0], drop.rng_state[1]);
     const long long total = (long long)rows * H;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(e / H), hcol = (int)(e % H);
         const float* xr = x + (size_t)r * ldx + c0;
         float v = b[hcol] + W[hcol * 3 + 0] * xr[0] + W[hcol * 3 + 1] * xr[1] + W[hcol * 3 + 2] * xr[2];
-        if (drop.p > 0.f) v *= drop1(drop, seed, step, (unsigned long long)e);
+        if (drop.p > 0.f) v *= drop_keep(drop, dkey, (unsigned long long)e);
         out[e] = v + pe[(size_t)(r % L) * H + hcol];
     }
 }
@@ -286,11 +283,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                                                         int ldx, int c0, float* __restrict__ part, int rows, int H,
                                                         int rows_per_block, DropCfg drop) {
     __shared__ float red[4][4][64];
-    unsigned long long seed = 0, step = 0;
-    if (drop.p > 0.f) {
-        seed = drop.rng_state[0];
-        step = drop.rng_state[1];
-    }
+    unsigned dkey = 0;
+    if (drop.p > 0.f) dkey = drop_key(drop, drop.rng_state[0], drop.rng_state[1]);
     const int hcol = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ry = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -298,7 +292,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     if (hcol < H)
         for (int r = r0 + ry; r < r1; r += 4) {
             float d = dy[(size_t)r * H + hcol];
-            if (drop.p > 0.f) d *= drop1(drop, seed, step, (unsigned long long)r * H + hcol);
+            if (drop.p > 0.f) d *= drop_keep(drop, dkey, (unsigned long long)r * H + hcol);
             const float* xr = x + (size_t)r * ldx + c0;
             a0 += d * xr[0];
             a1 += d * xr[1];
@@ -325,13 +319,13 @@ __global__ void bcast_rows_kernel(const float* __restrict__ p0, const float* __r
     }
 }
 
-// out = dy * keep(site, elem)   (dropout backward; identical Philox stream as the forward site)
+// out = dy * keep(site, elem)   (dropout backward; the same stream as the forward site)
 __global__ void dropout_bwd_kernel(const float* __restrict__ dy, float* __restrict__ out, long long n, DropCfg drop) {
-    const unsigned long long seed = drop.rng_state[0], step = drop.rng_state[1];
+    const unsigned dkey = drop_key(drop, drop.rng_state[0], drop.rng_state[1]);
     const long long nq = (n + 3) / 4;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
         float f[4];
-        drop4(drop, seed, step, (unsigned long long)q, f);
+        drop4(drop, dkey, (unsigned long long)q, f);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const long long i = q * 4 + e;

@@ -163,7 +163,7 @@ def test_attention_dropout_consistent_between_forward_and_backward():
 
 def test_attention_dropout_gradients_match_autograd_with_extracted_mask():
     """Recover the kernel's dropout mask (V = identity makes O = P*keep), then check dQ/dK/dV against torch autograd
-    evaluated with that explicit mask: forward, dQ kernel and dK/dV kernel must all regenerate the same Philox mask."""
+    evaluated with that explicit mask: forward, dQ kernel and dK/dV kernel must all regenerate the same mask."""
     L = _hip()
     torch.manual_seed(4)
     B, nh, T, S, dh, p = 2, 2, 40, 16, 16, 0.3
