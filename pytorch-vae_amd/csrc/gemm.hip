@@ -19,6 +19,7 @@
 //   row-contiguous source: [k][rows] floats; a lane reads [8t+4h+j][row0 + lane&31] with
 //                         ds_read_b32 (32 consecutive dwords per half: conflict free).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -194,7 +195,6 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int ro
 // time and unrolled 4x (a fully unrolled generic epilogue cost every GEMM ~9 %: 292 -> 320 us on 16384x2048x512).
 template <bool A_KC, bool B_KC, int BKT, int MODE>
 __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const GemmArgs g) {
-    const int mode = (MODE >= 0) ? MODE : g.mode;
     constexpr int A_TILE = Tile<BKT>::A_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // stage s: A tile at smem + 2*s*A_TILE, B tile right behind it
@@ -244,13 +244,6 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
         if (inB && fullk) load_tile_fast<B_KC, BKT>(g.B, g.ldb, n0, (k0_), tid, rb);                          \
         else load_tile<B_KC, BKT>(g.B, g.ldb, g.N, n0, (k0_), kend, g.vecB, tid, rb);                         \
     }
-    if (nk > 0) {
-        LOAD_AB(kbeg)
-        store_tile<A_KC, BKT>(AS(0), tid, ra);
-        store_tile<B_KC, BKT>(BS(0), tid, rb);
-    }
-    __syncthreads();
-
     // The epilogue's second input (residual stream / saved activation: 64 floats per lane, laid out as the epilogue
     // reads them) is fetched two K-steps before the end so its HBM latency hides under the last MFMAs instead of
     // stalling the epilogue (+15 % on the FFN dgrad, +8 % on K=512 out-projections when loaded in place).
@@ -259,43 +252,75 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     const int kpre = nk >= 2 ? nk - 2 : 0;
     f32x4 auxr[16];
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more && !(g.flags & 4)) LOAD_AB(kbeg + (kt + 1) * BKT)
-        if (pre_aux && kt == kpre) {
+    // FASTL: both operand tiles in bounds, 16-byte addressable and K a multiple of the K-step (block-uniform): a
+    // branch-free steady state (unconditional fast loads / LDS stores, last step peeled).  Everything else takes the
+    // checked loop.  Keeping the two apart (like the epilogue) keeps the hot loop compact and contiguous.
+    auto mainloop = [&](auto fast_c) {
+        constexpr bool FASTL = decltype(fast_c)::value;
+        auto load_ab = [&](int k0) {
+            if (FASTL) {
+                load_tile_fast<A_KC, BKT>(g.A, g.lda, m0, k0, tid, ra);
+                load_tile_fast<B_KC, BKT>(g.B, g.ldb, n0, k0, tid, rb);
+            } else if (!(g.flags & 4)) {
+                LOAD_AB(k0)
+            }
+        };
+        auto prefetch_aux = [&]() {
             const float* ap = g.aux_in + (size_t)(m0 + wm * 64 + (lane >> 4)) * g.ldaux + n0 + wn * 64 + (lane & 15) * 4;
 #pragma unroll
             for (int q = 0; q < 16; ++q) auxr[q] = *reinterpret_cast<const f32x4*>(ap + (size_t)(q * 4) * g.ldaux);
-        }
-        const float* a_s = AS(cur);
-        const float* b_s = BS(cur);
+        };
+        auto compute = [&](int cur) {
+            const float* a_s = AS(cur);
+            const float* b_s = BS(cur);
 #pragma unroll
-        for (int t = 0; t < BKT / 8; ++t) {
-            f32x4 fa[2], fb[2];
+            for (int t = 0; t < BKT / 8; ++t) {
+                f32x4 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_KC, BKT>(a_s, wm * 64 + i * 32 + l31, t, h);
+                for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_KC, BKT>(a_s, wm * 64 + i * 32 + l31, t, h);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_KC, BKT>(b_s, wn * 64 + j * 32 + l31, t, h);
+                for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_KC, BKT>(b_s, wn * 64 + j * 32 + l31, t, h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (!A_KC && do_rowsum && tid < BM) {
-            // A image is [k][m]: column tid of the tile summed over this K-step (conflict-free: 32 consecutive dwords)
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            }
+            if (!A_KC && do_rowsum && tid < BM) {
+                // A image is [k][m]: column tid of the tile summed over this K-step (conflict-free: 32 consecutive dwords)
 #pragma unroll
-            for (int k = 0; k < BKT; ++k) rs_acc += a_s[k * BM + tid];
-        }
-        if (more) {
-            store_tile<A_KC, BKT>(AS(cur ^ 1), tid, ra);
-            store_tile<B_KC, BKT>(BS(cur ^ 1), tid, rb);
+                for (int k = 0; k < BKT; ++k) rs_acc += a_s[k * BM + tid];
+            }
+        };
+        if (nk > 0) {
+            if (FASTL) {
+                load_ab(kbeg);
+            } else {
+                LOAD_AB(kbeg)
+            }
+            store_tile<A_KC, BKT>(AS(0), tid, ra);
+            store_tile<B_KC, BKT>(BS(0), tid, rb);
         }
         __syncthreads();
-    }
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int cur = kt & 1;
+            load_ab(kbeg + (kt + 1) * BKT);
+            if (pre_aux && kt == kpre) prefetch_aux();
+            compute(cur);
+            store_tile<A_KC, BKT>(AS(cur ^ 1), tid, ra);
+            store_tile<B_KC, BKT>(BS(cur ^ 1), tid, rb);
+            __syncthreads();
+        }
+        if (nk > 0) {
+            if (pre_aux && nk == 1) prefetch_aux();
+            compute((nk - 1) & 1);
+            __syncthreads();
+        }
+    };
+    if (inA && inB && ((kend - kbeg) % BKT == 0) && !(g.flags & 4)) mainloop(std::true_type{});
+    else mainloop(std::false_type{});
     if (!A_KC && do_rowsum && tid < BM && m0 + tid < g.M) {
         if (g.rowsum_ws) g.rowsum_ws[(size_t)zsplit * g.M + m0 + tid] = rs_acc;
         else g.rowsum[m0 + tid] = (g.beta != 0.f) ? g.beta * g.rowsum[m0 + tid] + rs_acc : rs_acc;
@@ -325,73 +350,84 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     const int c4 = (lane & 15) * 4;
     const int col = n0 + wn * 64 + c4;
     const bool vecC = slab ? ((g.N & 3) == 0) : g.vecC;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[half][j][r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll(MODE >= 0 ? 8 : 4)
-    for (int it = 0; it < 8; ++it) {
-        const int rl = it * 4 + (lane >> 4);
-        const int row = m0 + wm * 64 + half * 32 + rl;
-        if (row >= g.M || col >= g.N) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * EP_LD + c4);
-        if (slab) {
-            float* dst = slab + (size_t)row * g.N + col;
-            if (vecC && col + 3 < g.N) *reinterpret_cast<f32x4*>(dst) = v;
-            else
-                for (int e = 0; e < 4; ++e) if (col + e < g.N) dst[e] = v[e];
-            continue;
-        }
-        const bool full = vecC && (col + 3 < g.N);
-        float* cptr = g.C + (size_t)row * g.ldc + col;
-        if (full) {
-            // ---- vector path: 4 consecutive columns
-            if (mode <= EPI_SIGMOID) {
-                if (g.bias) { const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col); v += bb; }
-                if (mode == EPI_RELU_DROP || mode == EPI_DROP_RESID) {
-                    if (mode == EPI_RELU_DROP)
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    if (g.drop.p > 0.f) {
-                        float f[4];
-                        drop4(g.drop, dkey, ((unsigned long long)row * g.N + col) >> 2, f);
-                        for (int e = 0; e < 4; ++e) v[e] *= f[e];
-                    }
-                    if (mode == EPI_DROP_RESID)
-                        v += pre_aux ? auxr[half * 8 + it] : *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
-                } else if (mode == EPI_GELU) {
-                    *reinterpret_cast<f32x4*>(g.aux_out + (size_t)row * g.ldaux + col) = v;
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                } else if (mode == EPI_SIGMOID) {
-                    for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-                }
-            } else {
-                const f32x4 a = pre_aux ? auxr[half * 8 + it] : *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
-                if (mode == EPI_MUL_POSMASK)
-                    for (int e = 0; e < 4; ++e) v[e] = (a[e] > 0.f) ? v[e] * g.drop.scale : 0.f;
-                else if (mode == EPI_MUL_GELUGRAD)
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+    // Whole tile in bounds and 16-byte addressable (block-uniform): vector-only epilogue, no per-element fallback
+    // code in the unrolled copies (the mixed form made the kernels 80-144 KB, most of it never executed).
+    // The generic kernel (MODE < 0) keeps a fast path for the linear epilogue only; the fused modes that matter have
+    // specialised kernels, the rest (and ragged tiles) take the compact per-element loop.
+    const bool tile_fast = vecC && (m0 + BM <= g.M) && (n0 + BN <= g.N) && (MODE >= 0 || g.mode == EPI_LINEAR);
+    auto epilogue = [&](auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        const int mode = (MODE >= 0) ? MODE : (FAST ? (int)EPI_LINEAR : g.mode);
+    #pragma unroll
+        for (int half = 0; half < 2; ++half) {
+        __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+        for (int j = 0; j < 2; ++j)
+    #pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[half][j][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+    #pragma unroll(FAST ? (MODE >= 0 ? 8 : 4) : 1)
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + (lane >> 4);
+            const int row = m0 + wm * 64 + half * 32 + rl;
+            if (!FAST && (row >= g.M || col >= g.N)) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * EP_LD + c4);
+            if (slab) {
+                float* dst = slab + (size_t)row * g.N + col;
+                if (FAST || (vecC && col + 3 < g.N)) *reinterpret_cast<f32x4*>(dst) = v;
                 else
-                    for (int e = 0; e < 4; ++e) v[e] *= a[e] * (1.f - a[e]);
+                    for (int e = 0; e < 4; ++e) if (col + e < g.N) dst[e] = v[e];
+                continue;
             }
-            if (g.beta != 0.f) { const f32x4 old = *reinterpret_cast<const f32x4*>(cptr); v += g.beta * old; }
-            *reinterpret_cast<f32x4*>(cptr) = v;
-        } else {
-            for (int e = 0; e < 4; ++e) {
-                if (col + e >= g.N) break;
-                float x = epilogue_value(g, v[e], row, col + e, dkey);
-                if (g.beta != 0.f) x += g.beta * cptr[e];
-                cptr[e] = x;
+            const bool full = FAST || (vecC && (col + 3 < g.N));
+            float* cptr = g.C + (size_t)row * g.ldc + col;
+            if (full) {
+                // ---- vector path: 4 consecutive columns
+                if (mode <= EPI_SIGMOID) {
+                    if (g.bias) { const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col); v += bb; }
+                    if (mode == EPI_RELU_DROP || mode == EPI_DROP_RESID) {
+                        if (mode == EPI_RELU_DROP)
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        if (g.drop.p > 0.f) {
+                            float f[4];
+                            drop4(g.drop, dkey, ((unsigned long long)row * g.N + col) >> 2, f);
+                            for (int e = 0; e < 4; ++e) v[e] *= f[e];
+                        }
+                        if (mode == EPI_DROP_RESID)
+                            v += (FAST && pre_aux) ? auxr[half * 8 + it] : *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
+                    } else if (mode == EPI_GELU) {
+                        *reinterpret_cast<f32x4*>(g.aux_out + (size_t)row * g.ldaux + col) = v;
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    } else if (mode == EPI_SIGMOID) {
+                        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+                    }
+                } else {
+                    const f32x4 a = (FAST && pre_aux) ? auxr[half * 8 + it] : *reinterpret_cast<const f32x4*>(g.aux_in + (size_t)row * g.ldaux + col);
+                    if (mode == EPI_MUL_POSMASK)
+                        for (int e = 0; e < 4; ++e) v[e] = (a[e] > 0.f) ? v[e] * g.drop.scale : 0.f;
+                    else if (mode == EPI_MUL_GELUGRAD)
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+                    else
+                        for (int e = 0; e < 4; ++e) v[e] *= a[e] * (1.f - a[e]);
+                }
+                if (g.beta != 0.f) { const f32x4 old = *reinterpret_cast<const f32x4*>(cptr); v += g.beta * old; }
+                *reinterpret_cast<f32x4*>(cptr) = v;
+            } else {
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= g.N) break;
+                    float x = epilogue_value(g, v[e], row, col + e, dkey);
+                    if (g.beta != 0.f) x += g.beta * cptr[e];
+                    cptr[e] = x;
+                }
             }
         }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+    };
+    if (tile_fast) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // Sum split-K slabs, add bias, C = beta*C + sum (+ the row-sum partials of the fused bias gradient).
@@ -510,6 +546,8 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
         rc = launch<true, true, 32, EPI_DROP_RESID>(g, splits, stream);       // out-projections / FFN2 (forward)
     } else if (splits == 1 && g.vecC && a_kcontig && b_kcontig && mode == EPI_RELU_DROP) {
         rc = launch<true, true, 32, EPI_RELU_DROP>(g, splits, stream);        // FFN1 (forward)
+    } else if (splits == 1 && g.vecC && a_kcontig && b_kcontig && mode == EPI_GELU) {
+        rc = launch<true, true, 32, EPI_GELU>(g, splits, stream);             // tokenizer FFN / fuse MLP (forward)
     } else if (splits == 1 && g.vecC && a_kcontig && !b_kcontig && mode == EPI_MUL_POSMASK) {
         rc = launch<true, false, 32, EPI_MUL_POSMASK>(g, splits, stream);     // FFN1 input gradient
     } else if (splits == 1 && g.vecC && a_kcontig && !b_kcontig && mode == EPI_MUL_GELUGRAD) {
