@@ -294,6 +294,28 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
                 for (int k = 0; k < BKT; ++k) rs_acc += a_s[k * BM + tid];
             }
         };
+        auto read_frags = [&](int cur, int t, f32x4 (&fa)[2], f32x4 (&fb)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_KC, BKT>(AS(cur), wm * 64 + i * 32 + l31, t, h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_KC, BKT>(BS(cur), wn * 64 + j * 32 + l31, t, h);
+        };
+        auto mfma_step = [&](const f32x4 (&fa)[2], const f32x4 (&fb)[2]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        };
+        auto rowsum_step = [&](int cur) {
+            if (!A_KC && do_rowsum && tid < BM) {
+                const float* a_s = AS(cur);
+#pragma unroll
+                for (int k = 0; k < BKT; ++k) rs_acc += a_s[k * BM + tid];
+            }
+        };
         if (nk > 0) {
             if (FASTL) {
                 load_ab(kbeg);
@@ -304,6 +326,45 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
             store_tile<B_KC, BKT>(BS(0), tid, rb);
         }
         __syncthreads();
+        if (FASTL && !(g.flags & 32)) {
+            // Software pipeline across the barrier: the fragments of the LAST sub-step of tile kt are already in
+            // registers when the next tile is written to LDS and the block synchronises, and the first fragments of
+            // tile kt+1 are requested right after the barrier, so barrier skew and LDS latency sit under 16 MFMAs
+            // instead of in front of the next tile's first one.
+            constexpr int NT = BKT / 8;
+            f32x4 fa[2][2], fb[2][2];
+            read_frags(0, 0, fa[0], fb[0]);
+            for (int kt = 0; kt + 1 < nk; ++kt) {
+                const int cur = kt & 1;
+                load_ab(kbeg + (kt + 1) * BKT);
+                if (pre_aux && kt == kpre) prefetch_aux();
+#pragma unroll
+                for (int t = 0; t + 1 < NT; ++t) {
+                    read_frags(cur, t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+                    mfma_step(fa[t & 1], fb[t & 1]);
+                }
+                rowsum_step(cur);
+                store_tile<A_KC, BKT>(AS(cur ^ 1), tid, ra);
+                store_tile<B_KC, BKT>(BS(cur ^ 1), tid, rb);
+                __syncthreads();
+                read_frags(cur ^ 1, 0, fa[0], fb[0]);
+                __builtin_amdgcn_sched_barrier(0);      // or the scheduler hoists these MFMAs back above the barrier
+                mfma_step(fa[(NT - 1) & 1], fb[(NT - 1) & 1]);
+            }
+            {
+                const int cur = (nk - 1) & 1;
+                if (pre_aux && nk == 1) prefetch_aux();
+#pragma unroll
+                for (int t = 0; t + 1 < NT; ++t) {
+                    read_frags(cur, t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+                    mfma_step(fa[t & 1], fb[t & 1]);
+                }
+                rowsum_step(cur);
+                mfma_step(fa[(NT - 1) & 1], fb[(NT - 1) & 1]);
+                __syncthreads();
+            }
+            return;
+        }
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const int cur = kt & 1;
             load_ab(kbeg + (kt + 1) * BKT);
@@ -319,7 +380,7 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
             __syncthreads();
         }
     };
-    if (inA && inB && ((kend - kbeg) % BKT == 0) && !(g.flags & 4)) mainloop(std::true_type{});
+    if (nk > 0 && inA && inB && ((kend - kbeg) % BKT == 0) && !(g.flags & 4)) mainloop(std::true_type{});
     else mainloop(std::false_type{});
     if (!A_KC && do_rowsum && tid < BM && m0 + tid < g.M) {
         if (g.rowsum_ws) g.rowsum_ws[(size_t)zsplit * g.M + m0 + tid] = rs_acc;
