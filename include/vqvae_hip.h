@@ -59,7 +59,8 @@ int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, con
                    float* db, float beta, float* workspace, long long workspace_floats, vqh_stream_t stream);
 
 /* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
- * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads) */
+ * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads); bit 3 = BK=16 variant;
+ * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier */
 int vqh_gemm_set_flags(int flags);
 
 /* nn.LayerNorm forward/backward (eps 1e-5, biased variance); 35 instances on the path */
@@ -115,6 +116,8 @@ int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* 
                  const float* LSE, const float* dO, int lddo, float* Dsum, float* dQ, int lddq, float* dK, int lddk,
                  float* dV, int lddv, const unsigned char* kvalid, int B, int nh, int T, int S, int dh, int qkv_shared,
                  const unsigned long long* rng_state, unsigned drop_site, float drop_p, vqh_stream_t stream);
+/* diagnostic: bit 0 = do not use the fused short-sequence (T,S <= 64) kernels; returns the previous flags */
+int vqh_attn_set_flags(int flags);
 
 /* VectorQuantizerEMA (models/vq_vae.py:19-283) */
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,

@@ -408,9 +408,249 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dkv_kernel(const AttnArgs
     }
 }
 
+// ---- short sequences: fused backward ------------------------------------------------------------
+// T <= 64 and S <= 64 (every attention of the 64-residue / 64-token configs): one workgroup owns a whole
+// (batch, head).  Q, K, V and dO are staged into LDS ONCE with coalesced 16-byte loads (D = rowsum(dO*O) is reduced on
+// the way in), waves 0-1 produce dQ for 32 queries each while waves 2-3 produce dK/dV for 32 keys each, and the three
+// results leave through LDS as whole rows.  Against the two general kernels this halves the operand reads (both read
+// Q, K, V, dO) and replaces their per-lane row-strided 4-byte accesses by 16-byte coalesced ones: 268 MB instead of
+// ~400 MB per C2 call, 195 us -> see DESIGN.md.
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a) {
+    constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4, C4 = DH / 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;
+    float* Ks = Qs + 64 * LD;
+    float* Vs = Ks + 64 * LD;
+    float* Os = Vs + 64 * LD;              // dO
+    float* Ls = Os + 64 * LD;
+    float* Ds = Ls + 64;
+    unsigned* Rk = reinterpret_cast<unsigned*>(Ds + 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int hh = blockIdx.y, b = blockIdx.z;
+    const float* Qb = a.Q + (size_t)b * a.qbs + hh * DH;
+    const float* Kb = a.K + (size_t)b * a.kbs + hh * DH;
+    const float* Vb = a.V + (size_t)b * a.vbs + hh * DH;
+    const float* dOb = a.dO + (size_t)b * a.T * a.lddo + hh * DH;
+    const float* Ob = a.O + (size_t)b * a.T * a.ldo + hh * DH;
+    const unsigned char* kv = a.kvalid ? a.kvalid + (size_t)b * a.S : nullptr;
+    const size_t rowbase = ((size_t)b * a.nh + hh) * a.T;
+    unsigned long long seed = 0, step = 0;
+    if (a.drop.p > 0.f) { seed = a.drop.rng_state[0]; step = a.drop.rng_state[1]; }
+
+    // ---- stage operands (rows beyond T / S are zero) and reduce D
+#pragma unroll
+    for (int i = tid; i < 64 * C4; i += 256) {
+        const int r = i / C4, c = (i % C4) * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 qv = z, kk = z, vv = z, dov = z, ov = z;
+        if (r < a.T) {
+            qv = *reinterpret_cast<const f32x4*>(Qb + (size_t)r * a.ldq + c);
+            dov = *reinterpret_cast<const f32x4*>(dOb + (size_t)r * a.lddo + c);
+            ov = *reinterpret_cast<const f32x4*>(Ob + (size_t)r * a.ldo + c);
+        }
+        if (r < a.S) {
+            kk = *reinterpret_cast<const f32x4*>(Kb + (size_t)r * a.ldk + c);
+            vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)r * a.ldv + c);
+        }
+        *reinterpret_cast<f32x4*>(Qs + r * LD + c) = qv;
+        *reinterpret_cast<f32x4*>(Ks + r * LD + c) = kk;
+        *reinterpret_cast<f32x4*>(Vs + r * LD + c) = vv;
+        *reinterpret_cast<f32x4*>(Os + r * LD + c) = dov;
+        float dsum = dov[0] * ov[0] + dov[1] * ov[1] + dov[2] * ov[2] + dov[3] * ov[3];
+#pragma unroll
+        for (int off = C4 / 2; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+        if ((i % C4) == 0) Ds[r] = dsum;
+    }
+    if (tid < 64) {
+        Ls[tid] = (tid < a.T) ? a.LSE[rowbase + tid] : 0.f;
+        Rk[tid] = (a.drop.p > 0.f) ? attn_rowkey(a.drop, seed, step, (unsigned long long)(rowbase + tid)) : 0u;
+    }
+    __syncthreads();
+
+    f32x16 acc0[ND], acc1[ND];             // query waves: acc0 = dQ^T ; key waves: acc0 = dK^T, acc1 = dV^T
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[d][r] = 0.f; acc1[d][r] = 0.f; }
+
+    if (wave < 2) {
+        // ---- dQ for queries 32*wave .. +31 (the general dq kernel with every operand in LDS)
+        const int q = wave * 32 + l31;
+        if (wave * 32 < a.T) {
+            f32x4 qf[NG], dof[NG];
+#pragma unroll
+            for (int t = 0; t < NG; ++t) {
+                qf[t] = *reinterpret_cast<const f32x4*>(Qs + q * LD + 8 * t + 4 * h);
+                qf[t] *= a.scale;
+                dof[t] = *reinterpret_cast<const f32x4*>(Os + q * LD + 8 * t + 4 * h);
+            }
+            const float dsum = Ds[q], lse = Ls[q];
+            const unsigned rowkey = Rk[q];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int s0 = sub * 32;
+                if (s0 >= a.S) break;
+                f32x16 sacc, dpacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+                const float* kr = Ks + (s0 + l31) * LD + 4 * h;
+                const float* vr = Vs + (s0 + l31) * LD + 4 * h;
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + 8 * t);
+                    const f32x4 vf = *reinterpret_cast<const f32x4*>(vr + 8 * t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], sacc, 0, 0, 0);
+                        dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[t][j], dpacc, 0, 0, 0);
+                    }
+                }
+                float ds[16], keep[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep[r] = (a.drop.p > 0.f) ? attn_keep(a.drop, rowkey, s0 + kmap(r, h)) : 1.f;
+                const int keyl = s0 + l31;
+                const unsigned char vb = (kv && keyl < a.S) ? kv[keyl] : (unsigned char)1;
+                const unsigned int vmask = (unsigned int)__ballot((keyl < a.S) && vb != 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = (vmask >> kmap(r, h)) & 1u;
+                    const float pe = __expf(fminf(sacc[r] - lse, 80.f));
+                    const float p = ok ? pe : 0.f;
+                    ds[r] = p * (dpacc[r] * keep[r] - dsum);
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const int dcol = d * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float kk = (dcol < DH) ? Ks[(s0 + kmap(r, h)) * LD + dcol] : 0.f;
+                        acc0[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, ds[r], acc0[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
+        // ---- dK, dV for keys 32*(wave-2) .. +31 (the general dkv kernel with every operand in LDS)
+        const int key = (wave - 2) * 32 + l31;
+        if ((wave - 2) * 32 < a.S) {
+            const bool kin = key < a.S;
+            const bool kok = kin && (!kv || kv[key]);
+            f32x4 kf[NG], vf[NG];
+#pragma unroll
+            for (int t = 0; t < NG; ++t) {
+                kf[t] = *reinterpret_cast<const f32x4*>(Ks + key * LD + 8 * t + 4 * h);
+                vf[t] = *reinterpret_cast<const f32x4*>(Vs + key * LD + 8 * t + 4 * h);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int q0 = sub * 32;
+                if (q0 >= a.T) break;
+                f32x16 sacc, dpacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+                const float* qr = Qs + (q0 + l31) * LD + 4 * h;
+                const float* orow = Os + (q0 + l31) * LD + 4 * h;
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    f32x4 qf = *reinterpret_cast<const f32x4*>(qr + 8 * t);
+                    qf *= a.scale;
+                    const f32x4 dof = *reinterpret_cast<const f32x4*>(orow + 8 * t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[t][j], sacc, 0, 0, 0);
+                        dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[j], vf[t][j], dpacc, 0, 0, 0);
+                    }
+                }
+                float pd[16], ds[16], keep[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    keep[r] = (a.drop.p > 0.f) ? attn_keep(a.drop, Rk[q0 + kmap(r, h)], key) : 1.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = q0 + kmap(r, h);
+                    const bool ok = kok && (ql < a.T);
+                    const float pe = __expf(fminf(sacc[r] - Ls[ql], 80.f));
+                    const float p = ok ? pe : 0.f;
+                    pd[r] = p * keep[r];
+                    ds[r] = p * (dpacc[r] * keep[r] - Ds[ql]);
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const int dcol = d * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = q0 + kmap(r, h);
+                        const float dov = (dcol < DH) ? Os[ql * LD + dcol] : 0.f;
+                        const float qv = (dcol < DH) ? Qs[ql * LD + dcol] : 0.f;
+                        acc1[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(dov, pd[r], acc1[d], 0, 0, 0);
+                        acc0[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[r], acc0[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                       // every wave is done reading the staged operands
+
+    // ---- results -> LDS as [row][d] (registers 4g..4g+3 of an accumulator are 4 consecutive d), then whole rows out
+    {
+        const int row = (wave & 1) * 32 + l31;
+        float* dst0 = (wave < 2 ? Qs : Ks) + row * LD;
+        float* dst1 = Vs + row * LD;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * h;
+                if (dd >= DH) continue;
+                f32x4 x0, x1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x0[e] = acc0[d][4 * g4 + e] * a.scale; x1[e] = acc1[d][4 * g4 + e]; }
+                *reinterpret_cast<f32x4*>(dst0 + dd) = x0;
+                if (wave >= 2) *reinterpret_cast<f32x4*>(dst1 + dd) = x1;
+            }
+    }
+    __syncthreads();
+    float* dQb = a.dQ + (size_t)b * a.T * a.lddq + hh * DH;
+    float* dKb = a.dK + (size_t)b * a.S * a.lddk + hh * DH;
+    float* dVb = a.dV + (size_t)b * a.S * a.lddv + hh * DH;
+#pragma unroll
+    for (int i = tid; i < 64 * C4; i += 256) {
+        const int r = i / C4, c = (i % C4) * 4;
+        if (r < a.T) *reinterpret_cast<f32x4*>(dQb + (size_t)r * a.lddq + c) = *reinterpret_cast<const f32x4*>(Qs + r * LD + c);
+        if (r < a.S) {
+            *reinterpret_cast<f32x4*>(dKb + (size_t)r * a.lddk + c) = *reinterpret_cast<const f32x4*>(Ks + r * LD + c);
+            *reinterpret_cast<f32x4*>(dVb + (size_t)r * a.lddv + c) = *reinterpret_cast<const f32x4*>(Vs + r * LD + c);
+        }
+    }
+}
+
 bool aligned16(const void* p, int ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 3) == 0); }
 
+template <int DH>
+int launch_bwd_small(const AttnArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t smem = (size_t)(4 * 64 * (DH + 4) + 3 * 64) * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            vqh_set_error(hipGetErrorString(e));
+            return VQH_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_small_kernel<DH>), dim3(1, a.nh, a.B), dim3(256), smem, stream, a);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+int g_attn_flags = 0;
+
 }  // namespace
+
+// diagnostic switch (tests / probes): bit 0 = never take the short-sequence fused kernels
+extern "C" int vqh_attn_set_flags(int flags) { const int old = g_attn_flags; g_attn_flags = flags; return old; }
 
 extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                             int ldo, float* LSE, const unsigned char* kvalid, int B, int nh, int T, int S, int dh,
@@ -463,6 +703,15 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     a.qbs = (qkv_shared & 1) ? 0 : (long long)T * ldq; a.kbs = (qkv_shared & 2) ? 0 : (long long)S * ldk; a.vbs = (qkv_shared & 2) ? 0 : (long long)S * ldv;
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
     a.dO = dO; a.lddo = lddo; a.Dsum = Dsum; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+    if (T <= 64 && S <= 64 && aligned16(dQ, lddq) && aligned16(dK, lddk) && aligned16(dV, lddv) && !(g_attn_flags & 1)) {
+        int rc = VQH_OK;
+        switch (dh) {
+            case 16: rc = launch_bwd_small<16>(a, stream); break;
+            case 32: rc = launch_bwd_small<32>(a, stream); break;
+            default: rc = launch_bwd_small<64>(a, stream); break;
+        }
+        return rc;
+    }
     const int NWq = (T >= 128) ? 4 : 2, NWk = (S >= 128) ? 4 : 2;
     dim3 gq((T + 32 * NWq - 1) / (32 * NWq), nh, B), gk((S + 32 * NWk - 1) / (32 * NWk), nh, B);
 #define BWD(DH_)                                                                                          \

@@ -55,7 +55,7 @@ _PROTOS = {
     "vqh_adamw_step": "pppplppp",
 }
 _CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "l": C.c_longlong, "u": C.c_uint}
-EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_set_flags"] + list(_PROTOS)
+EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_set_flags", "vqh_attn_set_flags"] + list(_PROTOS)
 
 
 def lib():

@@ -114,7 +114,9 @@ def test_layernorm_forward_backward():
 
 
 @pytest.mark.parametrize("B,nh,T,S,dh,self_attn,ragged", [(3, 4, 24, 24, 16, True, True), (2, 8, 64, 64, 64, True, False),
-                                                          (2, 8, 70, 33, 64, False, True), (2, 2, 8, 100, 32, False, True)])
+                                                          (2, 8, 70, 33, 64, False, True), (2, 2, 8, 100, 32, False, True),
+                                                          (2, 4, 50, 64, 32, False, True), (3, 2, 64, 17, 64, False, True),
+                                                          (2, 2, 33, 64, 16, False, False)])
 def test_attention_forward_backward(B, nh, T, S, dh, self_attn, ragged):
     L = _hip()
     torch.manual_seed(T * S + dh)
@@ -159,6 +161,36 @@ def test_attention_dropout_consistent_between_forward_and_backward():
     o2 = torch.empty_like(o)
     L.call("vqh_attn_fwd", q, E, k, E, v, E, o2, E, lse, None, B, nh, T, S, dh, 0, None, 0, 0.0)
     assert float((o - o2).abs().max()) > 1e-3          # dropout really changed the output
+
+
+@pytest.mark.parametrize("T,S,dh,p", [(64, 64, 64, 0.1), (40, 64, 32, 0.25), (64, 24, 16, 0.0)])
+def test_attention_short_sequence_kernels_equal_general_kernels(T, S, dh, p):
+    """T,S <= 64 take fused single-workgroup kernels; they must reproduce the general flash kernels (same dropout
+    masks, same masking) to rounding."""
+    L = _hip()
+    torch.manual_seed(T + S + dh)
+    B, nh = 3, 4
+    E = nh * dh
+    q, do = torch.randn(B, T, E, device=DEV), torch.randn(B, T, E, device=DEV)
+    k, v = torch.randn(B, S, E, device=DEV), torch.randn(B, S, E, device=DEV)
+    lens = torch.randint(max(1, S // 2), S + 1, (B,))
+    valid = (torch.arange(S)[None] < lens[:, None]).to(DEV)
+    rng = torch.tensor([7, 5], device=DEV, dtype=torch.int64)
+    res = []
+    for flags in (0, 1):
+        old = L.lib().vqh_attn_set_flags(flags)
+        try:
+            o, lse = torch.empty(B, T, E, device=DEV), torch.empty(B * nh * T, device=DEV)
+            L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, valid, B, nh, T, S, dh, 0, rng, 5, p)
+            dq, dk, dv, dsum = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty(B * nh * T, device=DEV)
+            L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, valid, B, nh, T, S, dh, 0,
+                   rng, 5, p)
+            torch.cuda.synchronize()
+        finally:
+            L.lib().vqh_attn_set_flags(old)
+        res.append((o, lse, dq, dk, dv))
+    for x, y in zip(*res):
+        assert rel(x, y) < 2e-6
 
 
 def test_attention_dropout_gradients_match_autograd_with_extracted_mask():
