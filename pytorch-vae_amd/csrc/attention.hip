@@ -408,6 +408,137 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dkv_kernel(const AttnArgs
     }
 }
 
+// ---- short sequences: forward -----------------------------------------------------------------------
+// T <= 64 and S <= 64: one workgroup (2 waves) per (batch, head); Q, K, V staged once with coalesced 16-byte loads,
+// O leaves through LDS as whole rows (the general kernel's per-lane row-strided 4-byte stores touch 32-64 lines per
+// instruction).  Same arithmetic, masking and dropout stream as attn_fwd_kernel.
+template <int DH>
+__global__ __launch_bounds__(128, 2) void attn_fwd_small_kernel(const AttnArgs a) {
+    constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4, C4 = DH / 4;
+    __shared__ __attribute__((aligned(16))) float Qs[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Ks[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int hh = blockIdx.y, b = blockIdx.z;
+    const float* Qb = a.Q + (size_t)b * a.qbs + hh * DH;
+    const float* Kb = a.K + (size_t)b * a.kbs + hh * DH;
+    const float* Vb = a.V + (size_t)b * a.vbs + hh * DH;
+    const unsigned char* kv = a.kvalid ? a.kvalid + (size_t)b * a.S : nullptr;
+    const size_t rowbase = ((size_t)b * a.nh + hh) * a.T;
+    unsigned long long seed = 0, step = 0;
+    if (a.drop.p > 0.f) { seed = a.drop.rng_state[0]; step = a.drop.rng_state[1]; }
+#pragma unroll
+    for (int i = tid; i < 64 * C4; i += 128) {
+        const int r = i / C4, c = (i % C4) * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 qv = z, kk = z, vv = z;
+        if (r < a.T) qv = *reinterpret_cast<const f32x4*>(Qb + (size_t)r * a.ldq + c);
+        if (r < a.S) {
+            kk = *reinterpret_cast<const f32x4*>(Kb + (size_t)r * a.ldk + c);
+            vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)r * a.ldv + c);
+        }
+        *reinterpret_cast<f32x4*>(Qs + r * LD + c) = qv;
+        *reinterpret_cast<f32x4*>(Ks + r * LD + c) = kk;
+        *reinterpret_cast<f32x4*>(Vs + r * LD + c) = vv;
+    }
+    __syncthreads();
+    const int q = wave * 32 + l31;
+    if (wave * 32 < a.T) {
+        const unsigned rowkey = (a.drop.p > 0.f) ? attn_rowkey(a.drop, seed, step, (unsigned long long)(rowbase + q)) : 0u;
+        f32x4 qf[NG];
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            qf[t] = *reinterpret_cast<const f32x4*>(Qs + q * LD + 8 * t + 4 * h);
+            qf[t] *= a.scale;
+        }
+        f32x16 o[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int s0 = sub * 32;
+            if (s0 >= a.S) break;
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const float* kr = Ks + (s0 + l31) * LD + 4 * h;
+            f32x4 kfr[NG];
+#pragma unroll
+            for (int t = 0; t < NG; ++t) kfr[t] = *reinterpret_cast<const f32x4*>(kr + 8 * t);
+#pragma unroll
+            for (int t = 0; t < NG; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[t][j], qf[t][j], sacc, 0, 0, 0);
+            const int keyl = s0 + l31;
+            const unsigned char vb = (kv && keyl < a.S) ? kv[keyl] : (unsigned char)1;
+            const unsigned int vmask = (unsigned int)__ballot((keyl < a.S) && vb != 0);
+            float mx = -INFINITY;
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ok[r] = (vmask >> kmap(r, h)) & 1u;
+                mx = ok[r] ? fmaxf(mx, sacc[r]) : mx;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float corr = (m_new == -INFINITY) ? 1.f : __expf(m - m_new);
+            float psum = 0.f;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = ok[r] ? __expf(sacc[r] - m_new) : 0.f;
+                psum += p[r];
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            lsum = lsum * corr + psum;
+            m = m_new;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+            if (a.drop.p > 0.f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] *= attn_keep(a.drop, rowkey, s0 + kmap(r, h));
+            }
+            float vv[ND][16];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int dcol = d * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[d][r] = (dcol < DH) ? Vs[(s0 + kmap(r, h)) * LD + dcol] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[d][r], p[r], o[d], 0, 0, 0);
+        }
+        // O^T accumulator -> this wave's own rows of Qs (only this wave read them, and only into qf above)
+        const float inv = 1.f / lsum;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * h;
+                if (dd >= DH) continue;
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = o[d][4 * g4 + e] * inv;
+                *reinterpret_cast<f32x4*>(Qs + q * LD + dd) = x;
+            }
+        if (h == 0 && a.LSE && q < a.T) a.LSE[rowbase + q] = m + __logf(lsum);
+    }
+    __syncthreads();
+    float* Ob = a.O + (size_t)b * a.T * a.ldo + hh * DH;
+#pragma unroll
+    for (int i = tid; i < 64 * C4; i += 128) {
+        const int r = i / C4, c = (i % C4) * 4;
+        if (r < a.T) *reinterpret_cast<f32x4*>(Ob + (size_t)r * a.ldo + c) = *reinterpret_cast<const f32x4*>(Qs + r * LD + c);
+    }
+}
+
 // ---- short sequences: fused backward ------------------------------------------------------------
 // T <= 64 and S <= 64 (every attention of the 64-residue / 64-token configs): one workgroup owns a whole
 // (batch, head).  Q, K, V and dO are staged into LDS ONCE with coalesced 16-byte loads (D = rowsum(dO*O) is reduced on
@@ -667,6 +798,16 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     a.kvalid = kvalid; a.B = B; a.nh = nh; a.T = T; a.S = S; a.scale = 1.0f / sqrtf((float)dh);
     a.qbs = (qkv_shared & 1) ? 0 : (long long)T * ldq; a.kbs = (qkv_shared & 2) ? 0 : (long long)S * ldk; a.vbs = (qkv_shared & 2) ? 0 : (long long)S * ldv;
     a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    if (T <= 64 && S <= 64 && aligned16(O, ldo) && !(g_attn_flags & 1)) {
+        dim3 grid(1, nh, B);
+        switch (dh) {
+            case 16: hipLaunchKernelGGL((attn_fwd_small_kernel<16>), grid, dim3(128), 0, stream, a); break;
+            case 32: hipLaunchKernelGGL((attn_fwd_small_kernel<32>), grid, dim3(128), 0, stream, a); break;
+            default: hipLaunchKernelGGL((attn_fwd_small_kernel<64>), grid, dim3(128), 0, stream, a); break;
+        }
+        VQH_LAUNCH_CHECK();
+        return VQH_OK;
+    }
     // 4 waves (128 queries) share each staged K/V chunk when there are enough queries per (batch, head)
     const int NWq = (T >= 128) ? 4 : 2;
     dim3 grid((T + 32 * NWq - 1) / (32 * NWq), nh, B);
