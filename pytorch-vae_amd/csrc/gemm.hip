@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
     const bool tile_fast = vecC && (m0 + BM <= g.M) && (n0 + BN <= g.N) && (MODE >= 0 || g.mode == EPI_LINEAR);
     auto epilogue = [&](auto fast_c) {
         constexpr bool FAST = decltype(fast_c)::value;
+        constexpr int EPI_UNROLL = FAST ? (MODE >= 0 ? 8 : 4) : 1;
         const int mode = (MODE >= 0) ? MODE : (FAST ? (int)EPI_LINEAR : g.mode);
     #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const 
                 ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + l31] = acc[half][j][r];
         __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the wave's own LDS writes have landed
         __builtin_amdgcn_wave_barrier();
-    #pragma unroll(FAST ? (MODE >= 0 ? 8 : 4) : 1)
+    #pragma unroll EPI_UNROLL
         for (int it = 0; it < 8; ++it) {
             const int rl = it * 4 + (lane >> 4);
             const int row = m0 + wm * 64 + half * 32 + rl;
