@@ -186,6 +186,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     }
 }
 
+// LayerNorm weight / bias gradients from the per-block slabs [S][2][H]: column i < H goes to dw, i >= H to db.
+// Same fixed summation order as reduce_slabs_kernel.
+__global__ __launch_bounds__(1024) void reduce_slabs2_kernel(const float* __restrict__ slabs, int S, int H,
+                                                             float* __restrict__ dw, float* __restrict__ db, float beta) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx, n = 2 * H;
+    float s = 0.f;
+    if (i < n) {
+        int k = ty;
+        for (; k + 48 < S; k += 64) {
+            const float a = slabs[(size_t)k * n + i], b = slabs[(size_t)(k + 16) * n + i];
+            const float c = slabs[(size_t)(k + 32) * n + i], d = slabs[(size_t)(k + 48) * n + i];
+            s += (a + b) + (c + d);
+        }
+        for (; k < S; k += 16) s += slabs[(size_t)k * n + i];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][tx];
+        float* o = (i < H) ? dw + i : db + (i - H);
+        *o = (beta != 0.f) ? beta * (*o) + t : t;
+    }
+}
+
 // out[i] = beta*out[i] + sum_s slabs[s*stride + i]
 // block = 64 columns x 16 slab lanes: every thread sums S/16 slabs with independent loads, the 16 partials of
 // a column are combined through LDS in a fixed order (deterministic).
@@ -525,11 +553,8 @@ extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int 
 #undef LN_BWD
 #undef LN_BWD_V
     VQH_LAUNCH_CHECK();
-    // slab layout [blk][2][H]: dw = sum_blk slab[blk][0], db = sum_blk slab[blk][1]
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, workspace, nblk, (long long)2 * H,
-                       (long long)H, dw, beta);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, workspace + H, nblk,
-                       (long long)2 * H, (long long)H, db, beta);
+    // slab layout [blk][2][H]: dw = sum_blk slab[blk][0], db = sum_blk slab[blk][1]  (one launch for both)
+    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3((2 * H + 63) / 64), dim3(1024), 0, stream, workspace, nblk, H, dw, db, beta);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }

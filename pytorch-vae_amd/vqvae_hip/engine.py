@@ -30,6 +30,20 @@ LN_EPS = 1e-5
 VQ_EPS = 1e-5
 WS_FLOATS = 48 * 1024 * 1024
 
+# backward phases in completion order and the parameter-name prefixes each one finishes (see StepEngine._flatten)
+BWD_PHASES = (("from_code.", "mem_ln.", "decoder.", "query_embed.", "head_xyz.", "head_ss."),
+              ("tokenizer.", "to_code."),
+              ("fuse_mlp.", "ln_ss.", "ss_encoder.", "ss_input_proj."),
+              ("ln_geo.", "enc_ln.", "encoder.", "input_proj."))
+
+
+def _bwd_phase(name):
+    for i, prefixes in enumerate(BWD_PHASES):
+        if name.startswith(prefixes):
+            return i
+    raise KeyError(f"parameter {name!r} is not assigned to a backward phase")
+
+
 METRIC_KEYS = ["loss", "Reconstruction_Loss_XYZ", "XYZ_MSE_Raw", "XYZ_MSE_Aligned", "Reconstruction_Loss_SS",
                "SS_Accuracy", "VQ_Loss", "Geom_BondLength_Loss", "Geom_BondAngle_Loss", "Geom_Direction_Loss",
                "Geom_Dihedral_Loss", "Geom_Loss", "SS_TV", "Usage_Reg", "XYZ_TV2", "VQ_Perplexity", "VQ_DeadRatio",
@@ -77,10 +91,18 @@ class StepEngine:
     def _flatten(self):
         """Re-home every parameter into one flat buffer (views), plus flat grad / Adam moments."""
         named = list(self.m.named_parameters())
-        offs, total = {}, 0
-        for n, p in named:
-            offs[n] = total
-            total += (p.numel() + 3) // 4 * 4
+        # Layout = the order in which backward completes the gradients, so that each phase's gradients are one
+        # contiguous bucket whose all-reduce can start while the next phase still computes (SURVEY.md 8e):
+        #   decode_bwd | tokenize_bwd | encode_bwd (SS branch + fuse) | encode_bwd (geometry branch) | EMA statistics
+        offs, total, bounds = {}, 0, []
+        for ph in range(len(BWD_PHASES)):
+            lo = total
+            for n, p in named:
+                if _bwd_phase(n) == ph:
+                    offs[n] = total
+                    total += (p.numel() + 3) // 4 * 4
+            bounds.append((lo, total))
+        self.buckets = bounds
         q = getattr(self.m, "quantizer", None)
         self.n_stats = (q.K + q.K * q.D + 3) // 4 * 4 if q is not None else 0
         self.flat_p = torch.zeros(total, device=self.dev, dtype=torch.float32)
@@ -356,6 +378,11 @@ class StepEngine:
         return hf, h_geo, s
 
     def encode_bwd(self, d_hf):
+        self.encode_bwd_ss(d_hf)
+        self.encode_bwd_geo()
+
+    def encode_bwd_ss(self, d_hf):
+        """fuse_mlp and the secondary-structure encoder; leaves d(cat) for encode_bwd_geo."""
         c = self.ctx
         B, Lq, H = c["B"], c["L"], self.H
         ML, mask = B * Lq, c["mask"]
@@ -378,7 +405,12 @@ class StepEngine:
             self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask)
         call("vqh_embed_bwd", dres, c["x"], 6, 3, self.G["ss_input_proj.weight"], self.G["ss_input_proj.bias"], 0.0, ML, H,
              self.rng, 0, 0.0, self.ws, self.ws.numel())
-        # ---- geometry branch
+
+    def encode_bwd_geo(self):
+        c = self.ctx
+        B, Lq, H = c["B"], c["L"], self.H
+        ML, mask = B * Lq, c["mask"]
+        dcat, dres = self.buf["tmp.dcat"], self.buf["tmp.dres_seq"]
         xs = c["geo_xs"]
         dhg = self.T("tmp.dh", ML, H)
         self.ln_bwd("ln_geo", dcat, 2 * H, self.buf["enc_ln.y"], H, "ln_geo", dhg, H, False, ML)
@@ -765,11 +797,20 @@ class StepEngine:
 
     def backward(self):
         """Fill the flat gradient buffer from the d_rec / d_ze left by loss()."""
+        for ph in range(len(BWD_PHASES)):
+            self.backward_phase(ph)
+
+    def backward_phase(self, ph):
+        """Phase ph of backward; when it returns, bucket self.buckets[ph] of the flat gradient is final."""
         c = self.ctx
-        d_ze = c["d_ze"]
-        self.decode_bwd(c["d_rec"], d_ze, 1.0 if self.m.use_vq else 0.0)
-        d_hf = self.tokenize_bwd(d_ze)
-        self.encode_bwd(d_hf)
+        if ph == 0:
+            self.decode_bwd(c["d_rec"], c["d_ze"], 1.0 if self.m.use_vq else 0.0)
+        elif ph == 1:
+            c["d_hf"] = self.tokenize_bwd(c["d_ze"])
+        elif ph == 2:
+            self.encode_bwd_ss(c["d_hf"])
+        else:
+            self.encode_bwd_geo()
 
     def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         """Host -> device scalars of the next optimizer step (copied on the current stream, outside any graph)."""
@@ -789,17 +830,42 @@ class StepEngine:
         return world_size()
 
     def allreduce_grads(self):
-        """ONE RCCL all-reduce (sum) over [gradients | EMA statistics]; the 1/world gradient average is folded
-        into the clip coefficient (hyper[8]), the statistics are wanted as sums."""
+        """Blocking form (all buckets at once): sum over ranks of [gradients | EMA statistics]; the 1/world gradient
+        average is folded into the clip coefficient (hyper[8]), the statistics are wanted as sums."""
         from .parallel import allreduce_flat
         allreduce_flat(self.flat_gx, include_stats=self._pending_ema is not None, n_grad=self.n_flat)
 
+    def allreduce_bucket(self, ph, works):
+        """Start the sum all-reduce of bucket ph (the last one carries the EMA statistics behind it) without waiting:
+        RCCL runs it on its own stream behind everything queued so far, next to the following backward phase."""
+        from .parallel import allreduce_async
+        lo, hi = self.buckets[ph]
+        if ph == len(self.buckets) - 1 and self._pending_ema is not None:
+            hi = self.n_flat + self.n_stats
+        w = allreduce_async(self.flat_gx[lo:hi])
+        if w is not None:
+            works.append(w)
+
     # ------------------------------------------------------------------ fused training step
-    def _step_part_a(self, x_in, x_tgt, mask, weights, upd):
+    def _step_forward(self, x_in, x_tgt, mask, weights, upd):
         self.advance_rng()
         rec, z_e, z_q, idx, stats = self._forward_core(x_in, mask, upd)
         self.loss(rec, x_tgt, mask, z_e, z_q, stats, weights)
+
+    def _step_part_a(self, x_in, x_tgt, mask, weights, upd):
+        self._step_forward(x_in, x_tgt, mask, weights, upd)
         self.backward()
+
+    def _step_eager_dp(self, x_in, x_tgt, mask, weights, upd):
+        """world_size > 1 without graphs: backward phase by phase, each bucket's all-reduce overlapping the next phase."""
+        self._step_forward(x_in, x_tgt, mask, weights, upd)
+        works = []
+        for ph in range(len(BWD_PHASES)):
+            self.backward_phase(ph)
+            self.allreduce_bucket(ph, works)
+        for w in works:
+            w.wait()
+        self._step_part_b()
 
     def _step_part_b(self):
         self.finish_ema()
@@ -836,54 +902,77 @@ class StepEngine:
             ms.copy_(mask, non_blocking=True)
         g = self.graphs.get(key) if use_graph else None
         if g is not None:
-            g[0].replay()
-            if world > 1:
-                self._pending_ema = decay if (upd and m.num_quantizers == 1) else None
-                self.allreduce_grads()
-                self._pending_ema = None
-            if g[1] is not None:
-                g[1].replay()
+            if world == 1:
+                g[0].replay()
+                return self.metrics
+            # graph segments = forward+loss+phase 0, phases 1..3, optimizer; one async all-reduce after each phase
+            self._pending_ema = decay if (upd and m.num_quantizers == 1) else None
+            works = []
+            for ph in range(len(BWD_PHASES)):
+                g[ph].replay()
+                self.allreduce_bucket(ph, works)
+            for w in works:
+                w.wait()
+            self._pending_ema = None
+            g[-1].replay()
             return self.metrics
         seen = self._seen.get(key, 0)
         self._seen[key] = seen + 1
         can_capture = use_graph and seen >= 1 and not (world > 1 and m.use_vq and m.num_quantizers > 1)
         if not can_capture:
-            self._step_part_a(xs, xt, ms, weights, upd)
-            self.allreduce_grads()
-            self._step_part_b()
+            if world > 1:
+                self._step_eager_dp(xs, xt, ms, weights, upd)
+            else:
+                self._step_part_a(xs, xt, ms, weights, upd)
+                self._step_part_b()
             return self.metrics
         torch.cuda.synchronize()
-        ga = torch.cuda.CUDAGraph()
-        gb = None
+        graphs = []
         try:
             # thread_local: the RCCL watchdog thread may query events while this thread captures
             if world == 1:
+                ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     self._step_part_a(xs, xt, ms, weights, upd)
                     self._step_part_b()
+                graphs = [ga]
             else:
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    self._step_part_a(xs, xt, ms, weights, upd)
+                for ph in range(len(BWD_PHASES)):
+                    gp = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gp, capture_error_mode="thread_local"):
+                        if ph == 0:
+                            self._step_forward(xs, xt, ms, weights, upd)
+                        self.backward_phase(ph)
+                    graphs.append(gp)
                 pend = self._pending_ema
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     self._step_part_b()
+                graphs.append(gb)
                 self._pending_ema = pend
         except Exception as e:          # capture refused (driver / collective state): stay on eager launches
             print(f"[vqvae_hip] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
             self._seen[key] = -(1 << 30)
             self._pending_ema = None
             torch.cuda.synchronize()
-            self._step_part_a(xs, xt, ms, weights, upd)
-            self.allreduce_grads()
-            self._step_part_b()
+            if world > 1:
+                self._step_eager_dp(xs, xt, ms, weights, upd)
+            else:
+                self._step_part_a(xs, xt, ms, weights, upd)
+                self._step_part_b()
             return self.metrics
-        self.graphs[key] = (ga, gb)
-        ga.replay()
-        if world > 1:
-            self.allreduce_grads()
-            self._pending_ema = None
-            gb.replay()
+        self.graphs[key] = tuple(graphs)
+        if world == 1:
+            graphs[0].replay()
+            return self.metrics
+        works = []
+        for ph in range(len(BWD_PHASES)):
+            graphs[ph].replay()
+            self.allreduce_bucket(ph, works)
+        for w in works:
+            w.wait()
+        self._pending_ema = None
+        graphs[-1].replay()
         return self.metrics
 
     def eval_step(self, x, mask, weights):

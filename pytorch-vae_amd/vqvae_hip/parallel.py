@@ -2,15 +2,17 @@
 """Data-parallel plumbing of the training step: one process per GPU, torch.distributed backend "nccl"
 (= RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
-The step has exactly ONE exchange: a sum all-reduce over the flat buffer [gradients | EMA statistics]
+The step has ONE kind of exchange: sum all-reduces over the flat buffer [gradients | EMA statistics], issued as
+four buckets (the gradients of the four backward phases, in the order backward completes them; the statistics ride
+behind the last one) so that each bucket travels while the next phase computes:
   * gradients: DDP semantics (mean over ranks) -- the 1/world factor is folded into the clip coefficient
     that the fused AdamW kernel already multiplies into every gradient (hyper[8]), so no extra pass;
   * EMA statistics cnt[K] | sum[K,D]: wanted as SUMS over ranks, so that an N-rank step equals the
     single-process step on the concatenated batch (the reference's DDP never reduces
     them and broadcasts rank 0's codebook instead -- a documented, deliberate difference).
-The payload for config C2 is 172.5 MB + 0.13 MB, sent as one message: on xGMI (point-to-point links,
-7 x ~153 GB/s per GPU) a single large all-reduce is bandwidth-bound per link, many small ones are
-latency-bound."""
+The payload for config C2 is 172.5 MB + 0.13 MB in buckets of 69 / 17 / 31 / 55 MB: on xGMI (point-to-point links,
+7 x ~153 GB/s per GPU) large messages are bandwidth-bound per link, many small ones latency-bound, so the buckets
+follow the backward phases instead of a fixed small size."""
 import torch
 
 
@@ -40,3 +42,12 @@ def allreduce_flat(flat, include_stats=True, n_grad=None):
     if w > 1:
         torch.distributed.all_reduce(flat if (include_stats or n_grad is None) else flat[:n_grad])
     return 1.0 / w
+
+
+def allreduce_async(view):
+    """Start an in-place sum all-reduce of `view` (a contiguous slice of the flat buffer) and return its Work handle
+    (None for a single process).  With the nccl backend the collective is ordered behind the work already queued on
+    the current stream and runs on RCCL's own stream; handle.wait() makes the current stream wait for it."""
+    if world_size() > 1 and view.numel() > 0:
+        return torch.distributed.all_reduce(view, async_op=True)
+    return None

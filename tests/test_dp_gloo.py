@@ -38,12 +38,20 @@ def _worker(r, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     torch.distributed.init_process_group("gloo", rank=r, world_size=world)
-    from vqvae_hip.parallel import allreduce_flat, shard_bounds, world_size
+    from vqvae_hip.parallel import allreduce_async, allreduce_flat, shard_bounds, world_size
     x, mask = G.curve_batch(B, LQ, SEED + 1, ragged=False)
     lo, hi = shard_bounds(B)
     g, cnt, ssum, _ = _local(x[lo:hi], mask[lo:hi], G.BASE_LOSS_WEIGHTS)
     flat = torch.cat([g, cnt, ssum.reshape(-1)])
+    # the engine's exchange: four buckets started one after another without waiting, the statistics behind the last
+    bucketed = flat.clone()
+    n = g.numel()
+    cuts = [0, n // 3, n // 2, (3 * n) // 4, bucketed.numel()]
+    works = [allreduce_async(bucketed[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for w in works:
+        w.wait()
     scale = allreduce_flat(flat)
+    assert torch.equal(bucketed, flat), "bucketed all-reduce must equal the single-message one"
     assert world_size() == world and scale == 1.0 / world
     if r == 0:
         q.put(((flat[:g.numel()] * scale).numpy(), flat[g.numel():g.numel() + cnt.numel()].numpy().copy(),

@@ -243,3 +243,18 @@ def test_warm_start_filter_drops_quantizer_and_shape_mismatches():
     st = VQVAEExperiment._strip_model_prefix(cand)
     kept, sp, ss = VQVAEExperiment._filter_state_dict_for_warmstart(st, {"a": torch.zeros(2), "b": torch.zeros(4), "quantizer.embedding": torch.zeros(3)})
     assert list(kept) == ["a"] and sp == ["quantizer.embedding"] and ss == ["b"]
+
+
+def test_backward_phase_buckets_cover_every_parameter():
+    """The flat gradient buffer is laid out by backward phase (engine.BWD_PHASES) so that each phase's gradients form
+    one contiguous all-reduce bucket: every parameter of both shipped configurations must belong to exactly one phase."""
+    from vqvae_hip.engine import BWD_PHASES, _bwd_phase
+    import gen_inputs as G
+    from gen_inputs import O
+    for cfg_kw in (G.C2_MODEL, G.SMALL_RVQ, G.SMALL_AE):
+        names = list(O.param_shapes(O.make_cfg(**cfg_kw)))
+        phases = [_bwd_phase(n) for n in names]
+        assert set(phases) == set(range(len(BWD_PHASES)))
+        for n, ph in zip(names, phases):
+            assert sum(n.startswith(p) for p in BWD_PHASES[ph]) == 1
+            assert all(not n.startswith(p) for j, pr in enumerate(BWD_PHASES) if j != ph for p in pr), n
