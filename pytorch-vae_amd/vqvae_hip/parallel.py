@@ -10,7 +10,7 @@ behind the last one) so that each bucket travels while the next phase computes:
   * EMA statistics cnt[K] | sum[K,D]: wanted as SUMS over ranks, so that an N-rank step equals the
     single-process step on the concatenated batch (the reference's DDP never reduces
     them and broadcasts rank 0's codebook instead -- a documented, deliberate difference).
-The payload for config C2 is 172.5 MB + 0.13 MB in buckets of 69 / 17 / 31 / 55 MB: on xGMI (point-to-point links,
+The payload for config C2 is 172.5 MB + 0.13 MB in buckets of 68 / 26 / 28 / 51 MB: on xGMI (point-to-point links,
 7 x ~153 GB/s per GPU) large messages are bandwidth-bound per link, many small ones latency-bound, so the buckets
 follow the backward phases instead of a fixed small size."""
 import torch
