@@ -11,7 +11,7 @@ num_quantizers=1, codebook K=512, D=64, N=64 latent tokens) on a per-rank batch 
 curve tensors [256, 64, 6] already resident in HBM: forward (dropout 0.1 active) + 24-term loss +
 backward + RCCL all-reduce (N>1) + global-norm clip + AdamW + EMA codebook refresh, all fp32.
 Prints ONE JSON line (rank 0) with the whole-job samples/s, the roofline of the dominant kernel
-(the fp32-MFMA GEMM, measured live with HIP events) and a CPU baseline (the oracle on host cores).
+(the fp32-MFMA GEMM kernel with the largest share, measured live with HIP events) and a CPU baseline (the oracle on host cores).
 """
 import argparse
 import json
@@ -100,8 +100,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = torch.distributed
-    if world > 1:
+    selftest = os.environ.get("VQH_DP_SELFTEST") == "1"      # one-rank RCCL group: exercises the N>1 code path on one GPU
+    if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from models import vae_models
@@ -140,40 +142,38 @@ def main():
     value = B * world * args.steps / elapsed
     metrics = eng.metrics_dict(weights)
 
-    # ---- roofline of the dominant kernel: live HIP-event timing of every GEMM launch of 2 eager steps --------
+    # ---- roofline of the dominant kernel: HIP events around every GEMM main-kernel launch of 2 eager steps, recorded
+    # by the library on the launch stream and keyed by kernel instantiation (the names rocprofv3 prints) -------------
     roof = None
-    if rank == 0:
-        L.PROFILE = []
-        for _ in range(2):
+    prof = {}
+
+    def two_eager_steps():
+        for _ in range(2):      # every rank runs them (they contain the collective); only rank 0 reports
             eng.train_step(x, mask, weights, hp["lr"], hp["wd"], hp["clip"], use_graph=False)
-        torch.cuda.synchronize()
-        recs, L.PROFILE = L.PROFILE, None
-        by = {}
-        for (variant, M, N, K, e0, e1) in recs:
-            d = by.setdefault(variant, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += e0.elapsed_time(e1) * 1e-3
-            d[2] += 2.0 * M * N * K
-        tot_t = sum(d[1] for d in by.values())
-        tot_f = sum(d[2] for d in by.values())
-        # the three GEMM variants take about a third of the GEMM time each; report the forward (NT) one, whose event
-        # pair brackets exactly one kernel (the wgrad pair also covers its split-K reduce launch)
-        dom = "1,1" if "1,1" in by else max(by, key=lambda k: by[k][1])
-        n, t, f = by[dom]
+    prof = L.gemm_profile(two_eager_steps)
+    if rank == 0:
+        tot_t = sum(v[1] for v in prof.values())
+        tot_f = sum(v[2] for v in prof.values())
+        dom = max(prof, key=lambda k: prof[k][1])            # the instantiation with the largest summed time
+        n, t, f = prof[dom]
+        kname = "gemm_f32_mfma<%s, %s, 32, %d>" % (("true" if dom[0] else "false"), ("true" if dom[1] else "false"), dom[2])
         traffic = None
         try:   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")))
-            for kname, d in pm.items():
-                if "gemm_f32_mfma<true, true" in kname and "hbm_bytes_per_launch_corrected" in d:
+            for pk, d in pm.items():
+                if kname in pk and "hbm_bytes_per_launch_corrected" in d:
                     traffic = d["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": f"gemm_f32_mfma<{dom},32>", "achieved": round(f / t / 1e12, 2),
+        per_kernel = {"gemm_f32_mfma<%s, %s, 32, %d>" % (("true" if k[0] else "false"), ("true" if k[1] else "false"), k[2]):
+                      {"launches_per_step": v[0] // 2, "avg_launch_us": round(v[1] / v[0] * 1e6, 2),
+                       "achieved": round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(f / t / 1e12, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "launches_per_step": n // 2, "avg_launch_us": round(t / n * 1e6, 2),
                 "gflop_per_launch": round(f / n / 1e9, 3),
-                "all_gemm_variants": {"achieved": round(tot_f / tot_t / 1e12, 2), "time_ms_per_step": round(tot_t / 2 * 1e3, 3),
-                                      "gflop_per_step": round(tot_f / 2 / 1e9, 1)},
+                "all_gemm_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2), "time_ms_per_step": round(tot_t / 2 * 1e3, 3),
+                                     "gflop_per_step": round(tot_f / 2 / 1e9, 1), "per_kernel": per_kernel},
                 "step_level": {"gflop_per_sample": GFLOP_PER_SAMPLE_C2,
                                "achieved": round(value / world * GFLOP_PER_SAMPLE_C2 / 1e3, 2),
                                "frac": round(value / world * GFLOP_PER_SAMPLE_C2 / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)}}
@@ -195,7 +195,7 @@ def main():
                "recon_loss_xyz": round(metrics["Reconstruction_Loss_XYZ"], 6),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or selftest:
         dist.destroy_process_group()
 
 

@@ -63,6 +63,13 @@ int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, con
  * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier */
 int vqh_gemm_set_flags(int flags);
 
+/* Live timing of the GEMM main kernels with HIP events on their launch stream (bench.py's roofline figure):
+ * begin(), run eager (non-captured) steps, end(out) with out = double[4][9][3]: for operand layout (a_kcontig*2 +
+ * b_kcontig) and kernel template MODE+1 (0 = generic kernel, 1.. = epilogue-specialised): launches, kernel seconds,
+ * sum of 2*M*N*K.  The split-K reduce launch is not inside the bracket. */
+int vqh_gemm_profile_begin(void);
+int vqh_gemm_profile_end(double* out);
+
 /* nn.LayerNorm forward/backward (eps 1e-5, biased variance); 35 instances on the path */
 int vqh_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, float* mean,
                       float* rstd, int rows, int H, float eps, vqh_stream_t stream);

@@ -20,6 +20,7 @@
 //                         ds_read_b32 (32 consecutive dwords per half: conflict free).
 #include "common.h"
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -516,6 +517,13 @@ __global__ void splitk_reduce(const float* __restrict__ ws, int S, int M, int N,
     }
 }
 
+// ---- live per-kernel timing (bench.py): hipEvents around each main-kernel launch, on the launch stream ----------
+struct ProfRec { int slot; double flops; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+constexpr int PROF_MODES = 9;                       // template MODE -1..7 -> column MODE+1
+inline int prof_slot(bool a_kc, bool b_kc, int mode_t) { return ((a_kc ? 2 : 0) + (b_kc ? 1 : 0)) * PROF_MODES + mode_t + 1; }
+
 template <bool A_KC, bool B_KC, int BKT, int MODE = -1>
 int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     static bool attr_set = false;
@@ -531,12 +539,59 @@ int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     }
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles, 1, splits);
+    ProfRec rec{};
+    if (g_prof_on) {
+        rec.slot = prof_slot(A_KC, B_KC, MODE);
+        rec.flops = 2.0 * g.M * g.N * g.K;
+        if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess ||
+            hipEventRecord(rec.e0, stream) != hipSuccess) {
+            vqh_set_error("vqh_gemm: profiling events failed");
+            return VQH_ERR_LAUNCH;
+        }
+    }
     hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC, BKT, MODE>), grid, dim3(256), smem, stream, g);
     VQH_LAUNCH_CHECK();
+    if (g_prof_on) {
+        if (hipEventRecord(rec.e1, stream) != hipSuccess) {
+            vqh_set_error("vqh_gemm: profiling events failed");
+            return VQH_ERR_LAUNCH;
+        }
+        g_prof.push_back(rec);
+    }
     return VQH_OK;
 }
 
 }  // namespace
+
+// Timing of every GEMM main-kernel launch between begin and end (not under stream capture).  end() synchronises
+// the recorded events and fills out[4][9][3]: per (operand layout a_kc*2+b_kc, template MODE+1) the number of
+// launches, the summed kernel seconds and the summed 2*M*N*K.  The split-K reduce launch is outside the bracket.
+extern "C" int vqh_gemm_profile_begin(void) {
+    g_prof.clear();
+    g_prof_on = true;
+    return VQH_OK;
+}
+extern "C" int vqh_gemm_profile_end(double* out) {
+    g_prof_on = false;
+    if (out)
+        for (int i = 0; i < 4 * PROF_MODES * 3; ++i) out[i] = 0.0;
+    int rc = VQH_OK;
+    for (ProfRec& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+            vqh_set_error("vqh_gemm_profile_end: event query failed");
+            rc = VQH_ERR_LAUNCH;
+        } else if (out) {
+            out[r.slot * 3 + 0] += 1.0;
+            out[r.slot * 3 + 1] += (double)ms * 1e-3;
+            out[r.slot * 3 + 2] += r.flops;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    return rc;
+}
 
 static int g_gemm_flags = 1;
 extern "C" int vqh_gemm_set_flags(int flags) { const int old = g_gemm_flags; g_gemm_flags = flags; return old; }

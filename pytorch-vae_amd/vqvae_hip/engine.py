@@ -175,13 +175,7 @@ class StepEngine:
 
     def lin_wgrad(self, dy, lddy, x, ldx, rows, gW, gb):
         N, K = gW.shape         # gW[N,K] = dy[rows,N]^T . x[rows,K] ; gb[N] = column sums of dy (same launch)
-        if L.PROFILE is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         call("vqh_gemm_wgrad", rows, N, K, dy, lddy, x, ldx, gW, K, gb, 0.0, self.ws, self.ws.numel())
-        if L.PROFILE is not None:
-            e1.record()
-            L.PROFILE.append(("0,0", N, K, rows, e0, e1))
 
     def drop_bwd(self, dy, n, site, p, tag):
         """dy * keep-mask of a DROP_RESID site (identity when p == 0)."""
@@ -890,10 +884,12 @@ class StepEngine:
         x_in = self.augment_input(xt)             # eager, outside the graph (fresh torch random draws every step)
         upd = self._host_prologue()
         world = self.world()
+        from .parallel import dp_active
+        dp = dp_active()                          # data-parallel form of the step (world > 1)
         self.set_hyper(lr, weight_decay, clip, betas=getattr(self, "betas", (0.9, 0.999)), grad_scale=1.0 / world)
         decay = float(m.quantizer.decay) if m.use_vq else 0.0
         key = (tuple(x.shape), mask is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
-               world, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0),
+               world, dp, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0),
                x_in is xt, float(m.usage_entropy_lambda), self._soft_vq_key())
         xs = x_in
         ms = None
@@ -902,7 +898,7 @@ class StepEngine:
             ms.copy_(mask, non_blocking=True)
         g = self.graphs.get(key) if use_graph else None
         if g is not None:
-            if world == 1:
+            if not dp:
                 g[0].replay()
                 return self.metrics
             # graph segments = forward+loss+phase 0, phases 1..3, optimizer; one async all-reduce after each phase
@@ -918,9 +914,9 @@ class StepEngine:
             return self.metrics
         seen = self._seen.get(key, 0)
         self._seen[key] = seen + 1
-        can_capture = use_graph and seen >= 1 and not (world > 1 and m.use_vq and m.num_quantizers > 1)
+        can_capture = use_graph and seen >= 1 and not (dp and m.use_vq and m.num_quantizers > 1)
         if not can_capture:
-            if world > 1:
+            if dp:
                 self._step_eager_dp(xs, xt, ms, weights, upd)
             else:
                 self._step_part_a(xs, xt, ms, weights, upd)
@@ -930,7 +926,7 @@ class StepEngine:
         graphs = []
         try:
             # thread_local: the RCCL watchdog thread may query events while this thread captures
-            if world == 1:
+            if not dp:
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     self._step_part_a(xs, xt, ms, weights, upd)
@@ -955,14 +951,14 @@ class StepEngine:
             self._seen[key] = -(1 << 30)
             self._pending_ema = None
             torch.cuda.synchronize()
-            if world > 1:
+            if dp:
                 self._step_eager_dp(xs, xt, ms, weights, upd)
             else:
                 self._step_part_a(xs, xt, ms, weights, upd)
                 self._step_part_b()
             return self.metrics
         self.graphs[key] = tuple(graphs)
-        if world == 1:
+        if not dp:
             graphs[0].replay()
             return self.metrics
         works = []

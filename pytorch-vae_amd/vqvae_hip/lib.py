@@ -55,7 +55,7 @@ _PROTOS = {
     "vqh_adamw_step": "pppplppp",
 }
 _CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "l": C.c_longlong, "u": C.c_uint}
-EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_set_flags", "vqh_attn_set_flags"] + list(_PROTOS)
+EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_set_flags", "vqh_attn_set_flags", "vqh_gemm_profile_begin", "vqh_gemm_profile_end"] + list(_PROTOS)
 
 
 def lib():
@@ -68,6 +68,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.vqh_last_error.restype = C.c_char_p
         L.vqh_abi_version.restype = C.c_int
+        L.vqh_gemm_profile_end.argtypes = [C.c_void_p]
         for name, sig in _PROTOS.items():
             fn = getattr(L, name)
             fn.argtypes = [_CT[c] for c in sig]
@@ -101,19 +102,31 @@ def call(name, *args):
 EPI_LINEAR, EPI_RELU_DROP, EPI_GELU, EPI_DROP_RESID, EPI_SIGMOID, EPI_MUL_POSMASK, EPI_MUL_GELUGRAD, EPI_MUL_SIGGRAD = range(8)
 
 
-PROFILE = None   # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
-
-
 def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, mode=EPI_LINEAR, aux_in=None, aux_out=None,
          ldaux=0, beta=0.0, rng=None, site=0, p=0.0, ws=None):
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws)
-        e1.record()
-        PROFILE.append((f"{int(bool(a_kc))},{int(bool(b_kc))}", M, N, K, e0, e1))
-        return
     _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws)
+
+
+def gemm_profile(fn):
+    """Run fn() with the library's per-launch GEMM timing on; returns {(a_kc, b_kc, MODE): (launches, seconds, flops)}
+    keyed like the kernel's template arguments gemm_f32_mfma<a_kc, b_kc, 32, MODE>."""
+    import ctypes
+    lib().vqh_gemm_profile_begin()
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        out = (ctypes.c_double * (4 * 9 * 3))()
+        rc = lib().vqh_gemm_profile_end(ctypes.cast(out, ctypes.c_void_p))
+    if rc != 0:
+        raise VqhError(f"vqh_gemm_profile_end failed: {lib().vqh_last_error().decode()}")
+    res = {}
+    for lay in range(4):
+        for mc in range(9):
+            n, t, f = out[(lay * 9 + mc) * 3:(lay * 9 + mc) * 3 + 3]
+            if n > 0:
+                res[(lay >> 1, lay & 1, mc - 1)] = (int(n), t, f)
+    return res
 
 
 def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws):

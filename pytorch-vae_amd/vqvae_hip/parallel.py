@@ -13,7 +13,18 @@ behind the last one) so that each bucket travels while the next phase computes:
 The payload for config C2 is 172.5 MB + 0.13 MB in buckets of 68 / 26 / 28 / 51 MB: on xGMI (point-to-point links,
 7 x ~153 GB/s per GPU) large messages are bandwidth-bound per link, many small ones latency-bound, so the buckets
 follow the backward phases instead of a fixed small size."""
+import os
+
 import torch
+
+
+def dp_active():
+    """True when the step must run its data-parallel form (graph segments + bucketed all-reduce).  VQH_DP_SELFTEST=1
+    also selects it for an initialised ONE-rank group, so that the RCCL code path can be exercised on a one-GPU box."""
+    d = torch.distributed
+    if not (d.is_available() and d.is_initialized()):
+        return False
+    return d.get_world_size() > 1 or os.environ.get("VQH_DP_SELFTEST") == "1"
 
 
 def world_size():
@@ -48,6 +59,6 @@ def allreduce_async(view):
     """Start an in-place sum all-reduce of `view` (a contiguous slice of the flat buffer) and return its Work handle
     (None for a single process).  With the nccl backend the collective is ordered behind the work already queued on
     the current stream and runs on RCCL's own stream; handle.wait() makes the current stream wait for it."""
-    if world_size() > 1 and view.numel() > 0:
+    if dp_active() and view.numel() > 0:
         return torch.distributed.all_reduce(view, async_op=True)
     return None
