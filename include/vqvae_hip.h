@@ -126,6 +126,9 @@ int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* 
 /* diagnostic: bit 0 = do not use the fused short-sequence (T,S <= 64) kernels; returns the previous flags */
 int vqh_attn_set_flags(int flags);
 
+/* ids of positions outside `valid` (bytes, 1 = valid) become -1, which the statistics entry points below ignore:
+ * VectorQuantizerEMA.forward(mask=...) restricts the EMA statistics / usage histogram to valid positions (:192-205, :251-256) */
+int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long* out, int R, vqh_stream_t stream);
 /* VectorQuantizerEMA (models/vq_vae.py:19-283) */
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
                    int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);

@@ -351,17 +351,24 @@ class OracleVQVAE:
         dead = (use == 0).float().mean()
         return use, ppl, dead
 
-    def quantize(self, z_e, do_ema_update=True):
+    def quantize(self, z_e, do_ema_update=True, mask=None):
+        """mask [B, M] bool (optional, :175): only valid positions feed the EMA statistics (:192-197, :251-256) and,
+        single level only, the usage histogram (:202-205); every position is still quantized."""
         B, M, D = z_e.shape
         flat = z_e.reshape(-1, D)
         emb = self.sd["quantizer.embedding"]
         upd = self.training and do_ema_update
+        valid = mask.reshape(-1) if mask is not None else None
         if self.Q == 1:
             idx, _ = self._nearest(flat, emb)
             z_q = emb[idx].view(B, M, D)          # gather BEFORE the EMA refresh (:189 vs :191)
             if upd:
-                self._ema_update(flat.detach(), idx)
+                if valid is None:
+                    self._ema_update(flat.detach(), idx)
+                elif bool(valid.any()):
+                    self._ema_update(flat[valid].detach(), idx[valid])
             idx_all, idx_out = idx, idx.view(B, M)
+            idx_use = idx if valid is None else (idx[valid] if bool(valid.any()) else idx[:0])
         else:
             res, levels, parts = flat, [], []
             for lv in range(self.Q):
@@ -372,13 +379,17 @@ class OracleVQVAE:
                 levels.append(i_l + lo)
                 parts.append(zq_l)
                 if upd:
-                    self._ema_update(res.detach(), i_l + lo)
+                    if valid is None:
+                        self._ema_update(res.detach(), i_l + lo)
+                    elif bool(valid.any()):
+                        self._ema_update(res[valid].detach(), (i_l + lo)[valid])
                 res = res - zq_l
             idx_all = torch.cat(levels, 0)        # level-major flat [Q*B*M] (:260)
             idx_out = idx_all
+            idx_use = idx_all                     # the residual branch histograms every position (:264)
             z_q = torch.stack(parts, 0).sum(0).view(B, M, D)
         z_st = z_e + (z_q - z_e).detach()
-        use, ppl, dead = self._usage_stats(idx_all)
+        use, ppl, dead = self._usage_stats(idx_use)
         with torch.no_grad():
             self.sd["quantizer._ep_usage"].add_(use)
             self.sd["quantizer._ep_cnt"].add_(float(idx_all.shape[0]))

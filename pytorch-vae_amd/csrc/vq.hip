@@ -499,6 +499,21 @@ extern "C" int vqh_vq_finish(const float* zq_levels, int Q, const float* ze, int
 }
 
 // cnt[k0..k0+Kn), sum[k0..k0+Kn, :] are overwritten.
+// out[r] = valid[r] ? idx[r] : -1   (-1 matches no code in the statistics kernels: VectorQuantizerEMA(mask=...), :192-205)
+__global__ void vq_mask_ids_kernel(const long long* __restrict__ idx, const unsigned char* __restrict__ valid,
+                                   long long* __restrict__ out, int R) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) out[r] = valid[r] ? idx[r] : -1ll;
+}
+
+extern "C" int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long* out, int R, hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0, "vqh_vq_mask_ids: bad shape");
+    if (R == 0) return VQH_OK;
+    VQH_CHECK_ARG(idx && valid && out, "vqh_vq_mask_ids: null pointer");
+    hipLaunchKernelGGL(vq_mask_ids_kernel, dim3(blocks_for(R)), dim3(256), 0, stream, idx, valid, out, R);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
 extern "C" int vqh_vq_segment_sum(const float* rows, int ldr, const long long* idx, int R, int D, int k0, int Kn,
                                   float* cnt, float* sum, float* workspace, long long workspace_floats,
                                   hipStream_t stream) {

@@ -165,9 +165,8 @@ class VectorQuantizerEMA(nn.Module):
 
     def forward(self, z_e: Tensor, do_ema_update: bool = True, allow_reinit: bool = True,
                 mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-        """(z_q_st, z_q, indices, stats) like the reference; `mask` must be None (the model never passes one)."""
-        if mask is not None:
-            raise NotImplementedError("VectorQuantizerEMA(mask=...) is unused by the reference model and not on the HIP path")
+        """(z_q_st, z_q, indices, stats) like the reference (:170-283); `mask` [B, M] bool marks the positions that feed
+        the EMA statistics and (single level) the usage histogram (:192-205); the model itself never passes one (:869)."""
         if self._owner is None:
             raise _L.VqhError("quantizer is not attached to a VQVAE engine")
         B, M, D = z_e.shape
@@ -175,7 +174,8 @@ class VectorQuantizerEMA(nn.Module):
         eng.train = self.training
         eng.defer_ema = False
         with torch.no_grad():
-            z_st, z_q, idx, stats = eng.quantize(z_e.reshape(B * M, D).contiguous(), B, do_ema_update)
+            valid = None if mask is None else mask.to(device=z_e.device, dtype=torch.bool).reshape(B * M)
+            z_st, z_q, idx, stats = eng.quantize(z_e.reshape(B * M, D).contiguous(), B, do_ema_update, row_valid=valid)
         idx_out = idx.view(B, M).clone() if self.num_quantizers == 1 else idx.clone()
         return z_st.view(B, M, D).clone(), z_q.view(B, M, D).clone(), idx_out, stats.clone()
 
@@ -478,6 +478,51 @@ class VQVAE(nn.Module):
         eng = self._engine()
         eng.backward()
         eng.attach_grads()
+        if getattr(self, "_grad_monitor_enabled", False):
+            self._report_grads()
+
+    # ---- host-side gradient diagnostics (models/vq_vae.py:662-734).  The reference installs tensor hooks; here the
+    # gradients live in one flat buffer filled by the HIP backward, so the report runs once after backward. -----------
+    def enable_grad_monitor(self, enabled: bool = True):
+        self._grad_monitor_enabled = bool(enabled)
+        print("[Grad Monitor] Enabled" if enabled else "[Grad Monitor] Disabled")
+
+    def _report_grads(self):
+        for name, p in self.named_parameters():
+            g = p.grad
+            if g is None:
+                continue
+            if not bool(torch.isfinite(g).all()):
+                print(f"[GRAD-ERROR] {name}: NaN or Inf detected!")
+                continue
+            n = float(g.norm())
+            if n > 1e-6:
+                print(f"[GRAD] {name}: norm={n:.6f}, mean={float(g.mean()):.6f}, std={float(g.std()):.6f}")
+
+    def print_grad_summary(self):
+        if not self.training:
+            print("[Grad Summary] Model is in eval mode, no gradients")
+            return
+        # same name tests, in the same order, as the reference's grouping (:704-719)
+        groups = [("Geo branch", lambda n: "encoder" in n and "ss_" not in n),
+                  ("SS branch", lambda n: "ss_" in n),
+                  ("Fusion", lambda n: "fuse" in n),
+                  ("VQ", lambda n: "quantizer" in n),
+                  ("Decoder", lambda n: "decoder" in n or "head_ss" in n or "head_xyz" in n)]
+        count, total, with_grad = [0] * len(groups), [0.0] * len(groups), 0
+        for name, p in self.named_parameters():
+            if p.grad is None:
+                continue
+            with_grad += 1
+            for i, (_, belongs) in enumerate(groups):
+                if belongs(name):
+                    count[i] += 1
+                    total[i] += float(p.grad.norm())
+                    break
+        print(f"[Grad Summary] Total params with grad: {with_grad}")
+        for (label, _), c, t in zip(groups, count, total):
+            if c > 0:
+                print(f"  {label}: {c} params, avg_grad_norm={t / max(c, 1):.6f}")
 
     @torch.no_grad()
     def generate(self, x: Tensor, mask: Optional[Tensor] = None, **kwargs):

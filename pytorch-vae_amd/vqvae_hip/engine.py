@@ -504,8 +504,10 @@ class StepEngine:
         p = self._soft_vq_params() if self.m.use_vq else None
         return p
 
-    def quantize(self, z_e, B, do_ema_update):
-        """VectorQuantizerEMA.forward (models/vq_vae.py:170-283). z_e [B*N, D] -> z_st, z_q, idx, stats"""
+    def quantize(self, z_e, B, do_ema_update, row_valid=None):
+        """VectorQuantizerEMA.forward (models/vq_vae.py:170-283). z_e [B*N, D] -> z_st, z_q, idx, stats
+        row_valid [B*N] bool (the optional `mask` of :175): only valid positions feed the EMA statistics (:192-197,
+        :251-256) and, single level only, the usage histogram (:202-205); VQVAE.forward never passes one (:869)."""
         q = self.m.quantizer
         D, R = self.D, z_e.shape[0]
         Q, Kp, K = q.num_quantizers, q.K_per, q.K
@@ -518,6 +520,10 @@ class StepEngine:
         soft_on = self._soft_vq_params() is not None
         defer = bool((self.defer_ema and Q == 1) or soft_on)      # soft-VQ probabilities use the pre-refresh table
         upd = bool(self.train and do_ema_update)
+        if row_valid is not None:
+            row_valid = row_valid.reshape(-1).contiguous()
+            if not bool(row_valid.any()):          # no valid position: the reference skips the update (:196, :253)
+                upd = False
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size() > 1
         rows = z_e
@@ -533,8 +539,18 @@ class StepEngine:
             # per-code statistics of THIS level (other code ranges stay zero: the reference refreshes the whole table)
             call("vqh_memset", cnt, 0, K * 4)
             call("vqh_memset", ssum, 0, K * D * 4)
-            call("vqh_vq_segment_sum", rows, D, ids, R, D, lo, Kp, cnt, ssum, self.ws, self.ws.numel())
-            call("vqh_copy2d", cnt[lo:], Kp, usage[lo:], Kp, 1, Kp)
+            ids_stat = ids
+            if row_valid is not None:
+                if Q > 1:       # the residual branch histograms every position (:264): count before masking
+                    call("vqh_vq_segment_sum", rows, D, ids, R, D, lo, Kp, cnt, ssum, self.ws, self.ws.numel())
+                    call("vqh_copy2d", cnt[lo:], Kp, usage[lo:], Kp, 1, Kp)
+                    call("vqh_memset", cnt, 0, K * 4)
+                    call("vqh_memset", ssum, 0, K * D * 4)
+                ids_stat = self.T("vq.ids_valid", R, dtype=torch.int64)
+                call("vqh_vq_mask_ids", ids, row_valid, ids_stat, R)
+            call("vqh_vq_segment_sum", rows, D, ids_stat, R, D, lo, Kp, cnt, ssum, self.ws, self.ws.numel())
+            if row_valid is None or Q == 1:
+                call("vqh_copy2d", cnt[lo:], Kp, usage[lo:], Kp, 1, Kp)
             if upd and defer:
                 # single level: this step's z_q already used the old table (:189 precedes :191-197), so the refresh
                 # may run after backward, behind the combined gradient + statistics all-reduce

@@ -45,6 +45,7 @@ _PROTOS = {
     "vqh_vq_nearest": "pipipiiiifplp",
     "vqh_vq_gather": "pipipippiip",
     "vqh_vq_finish": "pipippiip",
+    "vqh_vq_mask_ids": "pppip",
     "vqh_vq_segment_sum": "pipiiiippplp",
     "vqh_vq_ema_apply": "pppppiifffp",
     "vqh_vq_usage_stats": "pifpppp",

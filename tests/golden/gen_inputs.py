@@ -94,3 +94,17 @@ def checksum(t):
     t = t.detach().double().reshape(-1)
     w = torch.arange(1, t.numel() + 1, dtype=torch.float64)
     return float((t * torch.cos(w)).sum())
+
+
+def vq_row_masks(B, M, seed, steps):
+    """Valid-position masks [B, M] for VectorQuantizerEMA(mask=...) fixtures: ragged prefixes; step 1 has no valid
+    position at all (the reference then skips the EMA update entirely, models/vq_vae.py:196)."""
+    g = torch.Generator().manual_seed(seed + 7777)
+    out = []
+    for s in range(steps):
+        lens = torch.randint(M // 4, M + 1, (B,), generator=g)
+        m = torch.arange(M)[None, :] < lens[:, None]
+        if s == 1:
+            m = torch.zeros(B, M, dtype=torch.bool)
+        out.append(m)
+    return out

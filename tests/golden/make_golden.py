@@ -68,8 +68,9 @@ def close_step(a, b, lr, what, nsteps=1):
 # 1. quantizer alone (models/vq_vae.py:170-283)
 # ------------------------------------------------------------------------------------------
 def vq_case(name, B, M, K_per, D, Q, seed, steps=1, centroid_init=False, train=True, scale=1.0,
-            dup_codes=False, store_inputs=False):
+            dup_codes=False, store_inputs=False, row_mask=False):
     R = B * M
+    masks = G.vq_row_masks(B, M, seed, steps) if row_mask else [None] * steps
     z_all = [G.vq_inputs(R, Q * K_per, D, seed + 17 * s, scale)[0] for s in range(steps)]
     emb0 = G.vq_inputs(R, Q * K_per, D, seed, scale)[1]
     if dup_codes:            # exact ties (first index must win) and exact hits (distance 0)
@@ -92,11 +93,11 @@ def vq_case(name, B, M, K_per, D, Q, seed, steps=1, centroid_init=False, train=T
     orc.training = train
     out = {"B": B, "M": M, "K_per": K_per, "D": D, "Q": Q, "seed": seed, "steps": steps,
            "centroid_init": int(centroid_init), "train": int(train), "scale": scale,
-           "dup_codes": int(dup_codes), "emb0_sum": G.checksum(emb0)}
+           "dup_codes": int(dup_codes), "emb0_sum": G.checksum(emb0), "row_mask": int(row_mask)}
     for s in range(steps):
         z = z_all[s].view(B, M, D)
-        zst, zq, idx, st = ref(z, do_ema_update=True, allow_reinit=False, mask=None)
-        o_zst, o_zq, o_idx, o_st = orc.quantize(z, do_ema_update=True)
+        zst, zq, idx, st = ref(z, do_ema_update=True, allow_reinit=False, mask=masks[s])
+        o_zst, o_zq, o_idx, o_st = orc.quantize(z, do_ema_update=True, mask=masks[s])
         assert torch.equal(idx.reshape(-1), o_idx.reshape(-1)), f"{name}: oracle indices differ"
         close(o_zq, zq, 1e-6, f"{name} z_q")
         close(o_st, st, 1e-5, f"{name} stats")
@@ -314,6 +315,8 @@ if __name__ == "__main__":
         vq_case("vq_rvq4_k64_d32", 8, 64, 64, 32, 4, seed=16, steps=2, centroid_init=True)
         vq_case("vq_rvq4_k1024_d512", 4, 64, 1024, 512, 4, seed=17, steps=1, centroid_init=True)
         vq_case("vq_tiny_store", 2, 8, 16, 8, 1, seed=18, steps=1, centroid_init=True, store_inputs=True)
+        vq_case("vq_k512_d64_masked", 16, 64, 512, 64, 1, seed=19, steps=3, centroid_init=True, scale=0.2, row_mask=True)
+        vq_case("vq_rvq4_k64_d32_masked", 8, 64, 64, 32, 4, seed=20, steps=3, centroid_init=True, row_mask=True)
     if want("model"):
         model_case("model_small_vq_full", G.SMALL_VQ, 6, 24, 21, False, G.BASE_LOSS_WEIGHTS, steps=2)
         model_case("model_small_vq_ragged", G.SMALL_VQ, 5, 37, 22, True, G.ALL_LOSS_WEIGHTS, smooth=True, steps=2)

@@ -225,7 +225,7 @@ def test_attention_dropout_gradients_match_autograd_with_extracted_mask():
 # ------------------------------------------------------------------------------------------------
 # quantizer against the golden vectors recorded from the reference
 # ------------------------------------------------------------------------------------------------
-from test_oracle import VQ_CASES, vq_setup, MODEL_CASES, EXTRA_CASES, model_inputs  # noqa: E402
+from test_oracle import VQ_CASES, vq_setup, vq_masks, MODEL_CASES, EXTRA_CASES, model_inputs  # noqa: E402
 
 
 @pytest.mark.parametrize("name", VQ_CASES)
@@ -241,9 +241,10 @@ def test_quantizer_matches_reference_golden(name):
         q.ema_embedding.copy_(emb0.to(DEV))
         q.ema_cluster_size.fill_(1.0)
     q.train(bool(int(g["train"])))
+    masks = vq_masks(g)
     for s in range(steps):
         z = zs[s].view(B, M, D).to(DEV)
-        zst, zq, idx, st = q(z, do_ema_update=True, allow_reinit=False, mask=None)
+        zst, zq, idx, st = q(z, do_ema_update=True, allow_reinit=False, mask=None if masks[s] is None else masks[s].to(DEV))
         got = idx.reshape(-1).cpu().numpy().astype(np.int32)
         want = g[f"idx_{s}"]
         bad = np.nonzero(got != want)[0]
@@ -258,7 +259,7 @@ def test_quantizer_matches_reference_golden(name):
             assert rel(q.embedding, g[f"emb_{s}"]) < 2e-6 and rel(q.ema_embedding, g[f"eemb_{s}"]) < 2e-6
         else:
             assert rel(q.embedding[:16], g[f"emb_head_{s}"]) < 2e-6
-        assert rel(q._ep_usage, g[f"ep_usage_{s}"]) == 0.0 and float(q._ep_cnt) == float(g[f"ep_cnt_{s}"])
+        assert rel(q._ep_usage, g[f"ep_usage_{s}"]) == 0.0 and float(q._ep_cnt) == float(np.asarray(g[f"ep_cnt_{s}"]).reshape(-1)[0])
 
 
 def test_quantizer_bit_exact_vs_oracle_at_c2_shape():

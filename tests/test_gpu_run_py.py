@@ -108,3 +108,27 @@ def test_generate_sample_and_autograd_bridge_api():
     with torch.no_grad():                                   # no tape in no_grad / eval: plain tensors
         ld2 = m.loss_function(*out, ss_weight=0.8, rmsd_weight=1.8)
     assert not ld2["loss"].requires_grad and abs(float(ld2["loss"]) - float(ld["loss"])) < 1e-6
+
+
+def test_gradient_diagnostics_report_after_hip_backward(capsys):
+    """enable_grad_monitor / print_grad_summary (models/vq_vae.py:662-734): host-side prints over the flat gradient buffer."""
+    import gen_inputs as G
+    from models import vae_models
+    m = vae_models["VQVAE"](**G.SMALL_VQ)
+    m.load_state_dict(G.model_state(G.SMALL_VQ, 2), strict=True)
+    m = m.to("cuda").train()
+    m._engine().drop_scale = 0.0
+    x, mask = G.curve_batch(3, 20, 4, ragged=True)
+    m.enable_grad_monitor(True)
+    ld = m.loss_function(*m(x.cuda(), mask.cuda()), ss_weight=0.8, rmsd_weight=1.8)
+    m.backward()
+    m.print_grad_summary()
+    out = capsys.readouterr().out
+    assert "[Grad Monitor] Enabled" in out and "[GRAD] to_code.weight: norm=" in out and "[GRAD-ERROR]" not in out
+    n_params = len(list(m.parameters()))
+    assert f"[Grad Summary] Total params with grad: {n_params}" in out
+    for label in ("Geo branch", "SS branch", "Fusion", "Decoder"):
+        assert f"  {label}: " in out
+    m.eval()
+    m.print_grad_summary()
+    assert "eval mode" in capsys.readouterr().out

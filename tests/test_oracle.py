@@ -22,7 +22,16 @@ def _close(a, b, tol, what=""):
 
 
 VQ_CASES = ["vq_k512_d64_fresh", "vq_k512_d64_cinit", "vq_k512_d64_eval", "vq_k512_d64_ties",
-            "vq_k8192_d256", "vq_rvq4_k64_d32", "vq_rvq4_k1024_d512", "vq_tiny_store"]
+            "vq_k8192_d256", "vq_rvq4_k64_d32", "vq_rvq4_k1024_d512", "vq_tiny_store",
+            "vq_k512_d64_masked", "vq_rvq4_k64_d32_masked"]
+
+
+def vq_masks(g):
+    """Valid-position masks of the VectorQuantizerEMA(mask=...) fixtures (None per step otherwise)."""
+    B, M, steps = int(g["B"]), int(g["M"]), int(g["steps"])
+    if "row_mask" in g and int(g["row_mask"]):
+        return G.vq_row_masks(B, M, int(g["seed"]), steps)
+    return [None] * steps
 
 
 def vq_setup(g):
@@ -51,10 +60,11 @@ def test_oracle_quantizer_matches_reference(name):
         sd["quantizer.ema_cluster_size"] = torch.ones(Q * K_per)
     orc = O.OracleVQVAE(sd, **cfg)
     orc.training = bool(int(g["train"]))
+    masks = vq_masks(g)
     for s in range(steps):
         z = zs[s].view(B, M, D)
         assert abs(G.checksum(z) - float(g[f"z_sum_{s}"])) < 1e-6
-        _, zq, idx, st = orc.quantize(z, do_ema_update=True)
+        _, zq, idx, st = orc.quantize(z, do_ema_update=True, mask=masks[s])
         assert np.array_equal(idx.reshape(-1).numpy().astype(np.int32), g[f"idx_{s}"]), "indices must be bit-exact"
         _close(st, g[f"stats_{s}"], 1e-5, "stats")
         _close(zq.reshape(-1, D)[:8], g[f"zq_head_{s}"], 1e-6, "zq")
