@@ -13,7 +13,8 @@
  *   - returns 0 on success, <0 on error; vqh_last_error() returns a thread-local message
  *   - safe to capture into a hipGraph (all step-varying scalars are read from device memory)
  *   - dropout masks are counter-hash functions of (seed, step, site, element): rng_state points to
- *     two device uint64 {seed, step}; backward regenerates the forward mask from the same site id
+ *     two device uint64 {seed, step}; backward regenerates the forward mask from the same site id;
+ *     drop probabilities are quantised to multiples of 2^-16 (keep scale 1/(1 - quantised p))
  */
 #ifndef VQVAE_HIP_H
 #define VQVAE_HIP_H

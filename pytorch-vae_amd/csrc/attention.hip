@@ -46,8 +46,8 @@ struct AttnArgs {
 
 // ---- attention dropout stream ----------------------------------------------------------------------
 // Attention probabilities use the counter hash of common.h keyed per row: element (row = (b*nh+head)*T + q, key)
-// keeps iff mix32(rowkey(row) ^ key*GOLDEN) * 2^-32 >= p, with rowkey = mix32 chain over (seed, step, site, row):
-// ~10 VALU ops per element.  Any kernel can evaluate any (row, key) directly, so the forward, dQ and dK/dV kernels
+// keeps iff its 16-bit half of mix32(rowkey(row) ^ (key/2)*GOLDEN) >= thr, with rowkey = mix32 chain over
+// (seed, step, site, row).  Any kernel can evaluate any (row, key) directly, so the forward, dQ and dK/dV kernels
 // regenerate identical masks whatever their register layout.
 __device__ __forceinline__ unsigned attn_rowkey(const DropCfg& d, unsigned long long seed, unsigned long long step,
                                                 unsigned long long row) {
@@ -56,9 +56,12 @@ __device__ __forceinline__ unsigned attn_rowkey(const DropCfg& d, unsigned long 
     k = mix32(k ^ (unsigned)(step >> 32) ^ (unsigned)(row >> 32));
     return mix32(k ^ (unsigned)row);
 }
+// keys 2j and 2j+1 of a row share one hash (16-bit draws, common.h); a lane's accumulator registers 4g..4g+3 hold 4
+// consecutive keys, so the query-side kernels evaluate two hashes per four probabilities
 __device__ __forceinline__ float attn_keep(const DropCfg& d, unsigned rowkey, int key) {
-    const unsigned r = mix32(rowkey ^ ((unsigned)key * 0x9E3779B9U));
-    return (r * 2.3283064365386963e-10f >= d.p) ? d.scale : 0.f;
+    const unsigned bits = mix32(rowkey ^ ((unsigned)(key >> 1) * 0x9E3779B9U));
+    const unsigned draw = (key & 1) ? (bits >> 16) : (bits & 0xffffu);
+    return (draw >= d.thr) ? d.scale : 0.f;
 }
 
 // ---- LDS staging -------------------------------------------------------------------------------
@@ -797,7 +800,7 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.LSE = LSE;
     a.kvalid = kvalid; a.B = B; a.nh = nh; a.T = T; a.S = S; a.scale = 1.0f / sqrtf((float)dh);
     a.qbs = (qkv_shared & 1) ? 0 : (long long)T * ldq; a.kbs = (qkv_shared & 2) ? 0 : (long long)S * ldk; a.vbs = (qkv_shared & 2) ? 0 : (long long)S * ldv;
-    a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    a.drop = make_drop(rng_state, drop_site, drop_p);
     if (T <= 64 && S <= 64 && aligned16(O, ldo) && !(g_attn_flags & 1)) {
         dim3 grid(1, nh, B);
         switch (dh) {
@@ -842,7 +845,7 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     a.LSE = const_cast<float*>(LSE); a.kvalid = kvalid; a.B = B; a.nh = nh; a.T = T; a.S = S;
     a.scale = 1.0f / sqrtf((float)dh);
     a.qbs = (qkv_shared & 1) ? 0 : (long long)T * ldq; a.kbs = (qkv_shared & 2) ? 0 : (long long)S * ldk; a.vbs = (qkv_shared & 2) ? 0 : (long long)S * ldv;
-    a.drop = DropCfg{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    a.drop = make_drop(rng_state, drop_site, drop_p);
     a.dO = dO; a.lddo = lddo; a.Dsum = Dsum; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
     if (T <= 64 && S <= 64 && aligned16(dQ, lddq) && aligned16(dK, lddk) && aligned16(dV, lddv) && !(g_attn_flags & 1)) {
         int rc = VQH_OK;

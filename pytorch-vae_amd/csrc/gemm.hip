@@ -661,7 +661,7 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
         g.vecC = ((al & 15) == 0 && (ldc & 3) == 0 && ((aux_in || aux_out) ? (ldaux & 3) == 0 : true) && (N & 3) == 0) ? 1 : 0;
     }
     g.mode = mode; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.beta = beta;
-    g.drop.rng_state = rng_state; g.drop.site = drop_site; g.drop.p = drop_p; g.drop.scale = 1.f / (1.f - drop_p);
+    g.drop = make_drop(rng_state, drop_site, drop_p);
     g.ws = nullptr;
     g.rowsum = rowsum;
     g.rowsum_ws = nullptr;

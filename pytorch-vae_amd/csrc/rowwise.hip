@@ -587,7 +587,7 @@ extern "C" int vqh_embed_fwd(const float* x, int ldx, int col0, const float* W, 
     if (rows == 0) return VQH_OK;
     VQH_CHECK_ARG(x && W && b && pe && out, "vqh_embed_fwd: null pointer");
     VQH_CHECK_ARG(drop_p == 0.f || rng_state, "vqh_embed_fwd: dropout needs rng_state");
-    DropCfg d{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    DropCfg d = make_drop(rng_state, drop_site, drop_p);
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks_for((long long)rows * H)), dim3(256), 0, stream, x, ldx, col0, W, b,
                        pe, out, rows, L, H, d);
     VQH_LAUNCH_CHECK();
@@ -606,7 +606,7 @@ extern "C" int vqh_embed_bwd(const float* dy, const float* x, int ldx, int col0,
     if (rb > 128) rb = 128;
     const int rpb = (rows + rb - 1) / rb > 0 ? (rows + rb - 1) / rb : 1;
     VQH_CHECK_ARG((long long)rb * 4 * H <= workspace_floats, "vqh_embed_bwd: workspace too small");
-    DropCfg d{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    DropCfg d = make_drop(rng_state, drop_site, drop_p);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((H + 63) / 64, rb), dim3(256), 0, stream, dy, x, ldx, col0, workspace, rows,
                        H, rpb, d);
     // slabs [blk][4][H]: gather weight column c into dW[h*3+c] needs a transposing reduce; reduce into a
@@ -634,7 +634,7 @@ extern "C" int vqh_dropout_bwd(const float* dy, float* out, long long n, const u
                                unsigned drop_site, float drop_p, hipStream_t stream) {
     VQH_CHECK_ARG(n >= 0 && drop_p > 0.f && drop_p < 1.f && rng_state, "vqh_dropout_bwd: bad argument");
     if (n == 0) return VQH_OK;
-    DropCfg d{rng_state, drop_site, drop_p, 1.f / (1.f - drop_p)};
+    DropCfg d = make_drop(rng_state, drop_site, drop_p);
     hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, stream, dy, out, n, d);
     VQH_LAUNCH_CHECK();
     return VQH_OK;
