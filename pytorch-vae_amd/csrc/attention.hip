@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs 
 
 // dK, dV : one wave per 32 keys (2 per block); Q / dO / LSE / D of 64 queries at a time staged through LDS.
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
     constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
     __shared__ __attribute__((aligned(16))) float Qs[64 * LD];
     __shared__ __attribute__((aligned(16))) float Os[64 * LD];
