@@ -60,7 +60,7 @@ int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, con
                    float* db, float beta, float* workspace, long long workspace_floats, vqh_stream_t stream);
 
 /* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
- * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads); bit 3 = BK=16 variant;
+ * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads);
  * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier */
 int vqh_gemm_set_flags(int flags);
 

@@ -195,7 +195,7 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int ro
 // registers are indexed by the unrolled loop counters); MODE < 0: generic kernel, epilogue selected by g.mode at run
 // time and unrolled 4x (a fully unrolled generic epilogue cost every GEMM ~9 %: 292 -> 320 us on 16384x2048x512).
 template <bool A_KC, bool B_KC, int BKT, int MODE>
-__global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_f32_mfma(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs g) {
     constexpr int A_TILE = Tile<BKT>::A_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // stage s: A tile at smem + 2*s*A_TILE, B tile right behind it
@@ -690,12 +690,7 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
     }
 
     int rc;
-    if (g.flags & 8) {          // BK=16 variant: 41 KB of LDS, 3 workgroups per CU
-        if (a_kcontig && b_kcontig) rc = launch<true, true, 16>(g, splits, stream);
-        else if (a_kcontig && !b_kcontig) rc = launch<true, false, 16>(g, splits, stream);
-        else if (!a_kcontig && b_kcontig) rc = launch<false, true, 16>(g, splits, stream);
-        else rc = launch<false, false, 16>(g, splits, stream);
-    } else if (splits == 1 && g.vecC && a_kcontig && b_kcontig && mode == EPI_DROP_RESID) {
+    if (splits == 1 && g.vecC && a_kcontig && b_kcontig && mode == EPI_DROP_RESID) {
         rc = launch<true, true, 32, EPI_DROP_RESID>(g, splits, stream);       // out-projections / FFN2 (forward)
     } else if (splits == 1 && g.vecC && a_kcontig && b_kcontig && mode == EPI_RELU_DROP) {
         rc = launch<true, true, 32, EPI_RELU_DROP>(g, splits, stream);        // FFN1 (forward)
