@@ -116,7 +116,10 @@ def test_layernorm_forward_backward():
 @pytest.mark.parametrize("B,nh,T,S,dh,self_attn,ragged", [(3, 4, 24, 24, 16, True, True), (2, 8, 64, 64, 64, True, False),
                                                           (2, 8, 70, 33, 64, False, True), (2, 2, 8, 100, 32, False, True),
                                                           (2, 4, 50, 64, 32, False, True), (3, 2, 64, 17, 64, False, True),
-                                                          (2, 2, 33, 64, 16, False, False)])
+                                                          (2, 2, 33, 64, 16, False, False),
+                                                          # T or S >= 128: the 4-wave general kernels, several K/V chunks
+                                                          (2, 4, 160, 200, 64, False, True), (1, 2, 256, 256, 32, True, True),
+                                                          (2, 2, 130, 70, 16, False, False)])
 def test_attention_forward_backward(B, nh, T, S, dh, self_attn, ragged):
     L = _hip()
     torch.manual_seed(T * S + dh)
@@ -143,14 +146,16 @@ def test_attention_forward_backward(B, nh, T, S, dh, self_attn, ragged):
     assert rel(dq, qd.grad) < 5e-6 and rel(dk, kd.grad) < 5e-6 and rel(dv, vd.grad) < 5e-6
 
 
-def test_attention_dropout_consistent_between_forward_and_backward():
+@pytest.mark.parametrize("T,S,dh", [(40, 40, 16), (160, 136, 64), (72, 200, 32)])
+def test_attention_dropout_consistent_between_forward_and_backward(T, S, dh):
     """With dropout on, backward must regenerate the forward mask: check d(sum(O*dO))/dV numerically-free via linearity:
     O is linear in V, so O(V) . dO == V . dV for the same mask."""
     L = _hip()
     torch.manual_seed(3)
-    B, nh, T, S, dh = 2, 4, 40, 40, 16
+    B, nh = 2, 4
     E = nh * dh
-    q, k, v, do = (torch.randn(B, T, E, device=DEV) for _ in range(4))
+    q, do = torch.randn(B, T, E, device=DEV), torch.randn(B, T, E, device=DEV)
+    k, v = torch.randn(B, S, E, device=DEV), torch.randn(B, S, E, device=DEV)
     rng = torch.tensor([99, 3], device=DEV, dtype=torch.int64)
     o, lse = torch.empty(B, T, E, device=DEV), torch.empty(B * nh * T, device=DEV)
     L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, None, B, nh, T, S, dh, 0, rng, 11, 0.25)
