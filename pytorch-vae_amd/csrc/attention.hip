@@ -84,8 +84,13 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[64 * LD];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * LD];
+    // K/V chunks of 64 keys in LDS.  PF (4-wave workgroups = long sequences): two stages; the next chunk is fetched into
+    // registers before the current one is consumed and stored behind it, one barrier per chunk instead of two.
+    extern __shared__ __attribute__((aligned(16))) float kv_smem[];
+    constexpr bool PF = (NW == 4);
+    constexpr int NPT = (64 * (DH / 4)) / (64 * NW), C4 = DH / 4;
+#define KST(s_) (kv_smem + (s_) * 2 * 64 * LD)
+#define VST(s_) (kv_smem + (s_) * 2 * 64 * LD + 64 * LD)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
@@ -111,12 +116,45 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) 
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m = -INFINITY, lsum = 0.f;
 
-    for (int c0 = 0; c0 < a.S; c0 += 64) {
+    f32x4 kreg[PF ? NPT : 1], vreg[PF ? NPT : 1];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool in = c0 + r < a.S;
+            kreg[j] = in ? *reinterpret_cast<const f32x4*>(Kb + (size_t)(c0 + r) * a.ldk + c) : z;
+            vreg[j] = in ? *reinterpret_cast<const f32x4*>(Vb + (size_t)(c0 + r) * a.ldv + c) : z;
+        }
+    };
+    auto lstore = [&](float* Kd, float* Vd) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
+            *reinterpret_cast<f32x4*>(Kd + r * LD + c) = kreg[j];
+            *reinterpret_cast<f32x4*>(Vd + r * LD + c) = vreg[j];
+        }
+    };
+    if (PF) {
+        gload(0);
+        lstore(KST(0), VST(0));
         __syncthreads();
-        stage_rows<DH, 64 * NW>(Ks, Kb, a.ldk, c0, a.S, tid);
-        stage_rows<DH, 64 * NW>(Vs, Vb, a.ldv, c0, a.S, tid);
-        __syncthreads();
-        if (!active) continue;
+    }
+    for (int c0 = 0, it = 0; c0 < a.S; c0 += 64, ++it) {
+        const float* Ks = KST(0);
+        const float* Vs = VST(0);
+        const bool more = c0 + 64 < a.S;
+        if (PF) {
+            Ks = KST(it & 1);
+            Vs = VST(it & 1);
+            if (more) gload(c0 + 64);
+        } else {
+            __syncthreads();
+            stage_rows<DH, 64 * NW>(KST(0), Kb, a.ldk, c0, a.S, tid);
+            stage_rows<DH, 64 * NW>(VST(0), Vb, a.ldv, c0, a.S, tid);
+            __syncthreads();
+        }
+        if (active) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int s0 = c0 + sub * 32;
@@ -176,7 +214,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) 
 #pragma unroll
                 for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[d][r], p[r], o[d], 0, 0, 0);
         }
+            }
+        if (PF) {
+            if (more) lstore(KST((it & 1) ^ 1), VST((it & 1) ^ 1));
+            __syncthreads();
+        }
     }
+#undef KST
+#undef VST
+
     if (q < a.T) {
         const float inv = 1.f / lsum;
         float* Op = a.O + ((size_t)b * a.T + q) * a.ldo + hh * DH;
@@ -195,8 +241,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) 
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     constexpr int NG = DH / 8, ND = (DH + 31) / 32, LD = DH + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[64 * LD];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * LD];
+    // K/V chunks of 64 keys in LDS.  PF (4-wave workgroups = long sequences): two stages; the next chunk is fetched into
+    // registers before the current one is consumed and stored behind it, one barrier per chunk instead of two.
+    extern __shared__ __attribute__((aligned(16))) float kv_smem[];
+    constexpr bool PF = (NW == 4);
+    constexpr int NPT = (64 * (DH / 4)) / (64 * NW), C4 = DH / 4;
+#define KST(s_) (kv_smem + (s_) * 2 * 64 * LD)
+#define VST(s_) (kv_smem + (s_) * 2 * 64 * LD + 64 * LD)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * (32 * NW) + wave * 32, hh = blockIdx.y, b = blockIdx.z;
     const int q = q0 + l31;
@@ -232,12 +283,45 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-    for (int c0 = 0; c0 < a.S; c0 += 64) {
+    f32x4 kreg[PF ? NPT : 1], vreg[PF ? NPT : 1];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool in = c0 + r < a.S;
+            kreg[j] = in ? *reinterpret_cast<const f32x4*>(Kb + (size_t)(c0 + r) * a.ldk + c) : z;
+            vreg[j] = in ? *reinterpret_cast<const f32x4*>(Vb + (size_t)(c0 + r) * a.ldv + c) : z;
+        }
+    };
+    auto lstore = [&](float* Kd, float* Vd) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
+            *reinterpret_cast<f32x4*>(Kd + r * LD + c) = kreg[j];
+            *reinterpret_cast<f32x4*>(Vd + r * LD + c) = vreg[j];
+        }
+    };
+    if (PF) {
+        gload(0);
+        lstore(KST(0), VST(0));
         __syncthreads();
-        stage_rows<DH, 64 * NW>(Ks, Kb, a.ldk, c0, a.S, tid);
-        stage_rows<DH, 64 * NW>(Vs, Vb, a.ldv, c0, a.S, tid);
-        __syncthreads();
-        if (!active) continue;
+    }
+    for (int c0 = 0, it = 0; c0 < a.S; c0 += 64, ++it) {
+        const float* Ks = KST(0);
+        const float* Vs = VST(0);
+        const bool more = c0 + 64 < a.S;
+        if (PF) {
+            Ks = KST(it & 1);
+            Vs = VST(it & 1);
+            if (more) gload(c0 + 64);
+        } else {
+            __syncthreads();
+            stage_rows<DH, 64 * NW>(KST(0), Kb, a.ldk, c0, a.S, tid);
+            stage_rows<DH, 64 * NW>(VST(0), Vb, a.ldv, c0, a.S, tid);
+            __syncthreads();
+        }
+        if (active) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int s0 = c0 + sub * 32;
@@ -280,7 +364,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs 
                 }
             }
         }
+            }
+        if (PF) {
+            if (more) lstore(KST((it & 1) ^ 1), VST((it & 1) ^ 1));
+            __syncthreads();
+        }
     }
+#undef KST
+#undef VST
+
     if (qok) {
         float* dQp = a.dQ + ((size_t)b * a.T + q) * a.lddq + hh * DH;
 #pragma unroll
@@ -761,6 +853,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
 
 bool aligned16(const void* p, int ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 3) == 0); }
 
+// query-side general kernels: K/V stages in dynamic LDS (two stages for the 4-wave form: 70 KB at DH = 64)
+template <int DH, int NW>
+int launch_kv(void (*kernel)(const AttnArgs), dim3 grid, const AttnArgs& a, hipStream_t stream) {
+    const size_t smem = (size_t)(NW == 4 ? 2 : 1) * 2 * 64 * (DH + 4) * sizeof(float);
+    static const void* configured[4] = {nullptr, nullptr, nullptr, nullptr};     // per <DH, NW>: forward and dQ kernels
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    bool seen = false;
+    for (const void* c : configured) seen = seen || (c == fn);
+    if (!seen) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            vqh_set_error(hipGetErrorString(e));
+            return VQH_ERR_LAUNCH;
+        }
+        for (const void*& c : configured)
+            if (!c) { c = fn; break; }
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * NW), smem, stream, a);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
 template <int DH>
 int launch_bwd_small(const AttnArgs& a, hipStream_t stream) {
     static bool attr_set = false;
@@ -814,17 +928,17 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     // 4 waves (128 queries) share each staged K/V chunk when there are enough queries per (batch, head)
     const int NWq = (T >= 128) ? 4 : 2;
     dim3 grid((T + 32 * NWq - 1) / (32 * NWq), nh, B);
-#define FWD(DH_)                                                                                         \
-    if (NWq == 4) hipLaunchKernelGGL((attn_fwd_kernel<DH_, 4>), grid, dim3(256), 0, stream, a);           \
-    else hipLaunchKernelGGL((attn_fwd_kernel<DH_, 2>), grid, dim3(128), 0, stream, a)
+#define FWD(DH_)                                                                                              \
+    if (NWq == 4) rc = launch_kv<DH_, 4>(attn_fwd_kernel<DH_, 4>, grid, a, stream);                            \
+    else rc = launch_kv<DH_, 2>(attn_fwd_kernel<DH_, 2>, grid, a, stream)
+    int rc = VQH_OK;
     switch (dh) {
         case 16: FWD(16); break;
         case 32: FWD(32); break;
         default: FWD(64); break;
     }
 #undef FWD
-    VQH_LAUNCH_CHECK();
-    return VQH_OK;
+    return rc;
 }
 
 extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
@@ -859,10 +973,12 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     const int NWq = (T >= 128) ? 4 : 2, NWk = (S >= 128) ? 4 : 2;
     dim3 gq((T + 32 * NWq - 1) / (32 * NWq), nh, B), gk((S + 32 * NWk - 1) / (32 * NWk), nh, B);
 #define BWD(DH_)                                                                                          \
-    if (NWq == 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH_, 4>), gq, dim3(256), 0, stream, a);           \
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH_, 2>), gq, dim3(128), 0, stream, a);                    \
+    if (NWq == 4) rc = launch_kv<DH_, 4>(attn_bwd_dq_kernel<DH_, 4>, gq, a, stream);                       \
+    else rc = launch_kv<DH_, 2>(attn_bwd_dq_kernel<DH_, 2>, gq, a, stream);                                \
+    if (rc != VQH_OK) return rc;                                                                          \
     if (NWk == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH_, 4>), gk, dim3(256), 0, stream, a);          \
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH_, 2>), gk, dim3(128), 0, stream, a)
+    int rc = VQH_OK;
     switch (dh) {
         case 16: BWD(16); break;
         case 32: BWD(32); break;
