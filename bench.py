@@ -57,7 +57,7 @@ def synthetic_batch(B, L, seed, device):
     return x.to(device), mask.to(device)
 
 
-def cpu_baseline(mp, weights, hp, B_cpu=32, L=64, steps=2):
+def cpu_baseline(mp, weights, hp, B_cpu=32, L=64, steps=8):
     """The oracle (kind 'port': our CPU restatement, verified against the reference by the golden vectors)
     timed on the host cores for the same model / step, on a bounded sample of the workload."""
     import gen_inputs as G
