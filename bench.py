@@ -108,6 +108,8 @@ def main():
 
     from models import vae_models
     from vqvae_hip import lib as L
+    if os.environ.get("VQH_GEMM_FLAGS"):                # tuning / diagnostic bits of vqh_gemm_set_flags (A/B runs)
+        L.lib().vqh_gemm_set_flags(int(os.environ["VQH_GEMM_FLAGS"]))
     mp, weights, hp = c2_setup()
     torch.manual_seed(hp["seed"])                        # same initial weights on every rank (DDP semantics)
     model = vae_models["VQVAE"](**mp).to(dev).train()

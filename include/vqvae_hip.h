@@ -61,7 +61,8 @@ int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, con
 
 /* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
  * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads);
- * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier */
+ * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier; bit 6 = no skinny-shape
+ * streaming kernels (everything on the MFMA tile kernel) */
 int vqh_gemm_set_flags(int flags);
 
 /* Live timing of the GEMM main kernels with HIP events on their launch stream (bench.py's roofline figure):

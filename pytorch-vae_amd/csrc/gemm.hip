@@ -553,6 +553,122 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict
     }
 }
 
+// ---- skinny shapes: the reconstruction heads (512 -> 3, models/vq_vae.py:763-764) ---------------------------------------
+// A 128x128 MFMA tile with 3 live columns wastes 98 % of the matrix work (60-90 us per launch); these shapes are pure
+// streaming of the wide operand (33 MB at C2) and run at HBM speed in simple kernels instead.  SK_MAX = largest small
+// dimension handled.
+constexpr int SK_MAX = 8;
+
+// C[M,N] = A[M,K] . B[N,K]^T + bias (+ beta C), N <= SK_MAX: a wave per row, lanes over K, N wave reductions.
+template <int N>     // compile-time small dimension: with a run-time bound every load sits behind its own branch
+__global__ __launch_bounds__(256) void skinny_n_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       int ldb, float* __restrict__ C, int ldc,
+                                                       const float* __restrict__ bias, float beta, int M, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        float acc[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = 0.f;
+        const float* ar = A + (size_t)row * lda;
+        for (int k = lane * 4; k < K; k += 256) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ar + k);
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(B + (size_t)n * ldb + k);
+                    acc[n] += av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2] + av[3] * bv[3];
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+                float v = acc[n];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0) {
+                    if (bias) v += bias[n];
+                    float* c = C + (size_t)row * ldc + n;
+                    *c = (beta != 0.f) ? beta * (*c) + v : v;
+                }
+            }
+    }
+}
+
+// C[M,N] = A[M,K] . B[K,N] (+ beta C), K <= SK_MAX: one output quad per thread.
+template <int K>
+__global__ __launch_bounds__(256) void skinny_k_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       int ldb, float* __restrict__ C, int ldc, float beta, int M, int N) {
+    const int nq = N >> 2;
+    const size_t total = (size_t)M * nq;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e / nq), col = (int)(e % nq) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K; ++k) v += A[(size_t)row * lda + k] * *reinterpret_cast<const f32x4*>(B + (size_t)k * ldb + col);
+        float* c = C + (size_t)row * ldc + col;
+        if (beta != 0.f) v += beta * *reinterpret_cast<const f32x4*>(c);
+        *reinterpret_cast<f32x4*>(c) = v;
+    }
+}
+
+// slab[z][m][n] = sum over the rows of chunk z of A[r,m] * B[r,n], rs[z][m] = sum A[r,m]   (M <= SK_MAX; A [K,M], B [K,N],
+// N <= 1024); the chunks are summed by splitk_reduce like any split-K launch.  The 256 threads are 256/(N/4) row slices x
+// N/4 column quads; the slices meet in LDS in a fixed order.
+template <int M>
+__global__ __launch_bounds__(256) void skinny_m_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       int ldb, float* __restrict__ slab, float* __restrict__ rs, int N, int K,
+                                                       int rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 4 * M];           // [slice][m][N]
+    __shared__ float red_rs[64][M];                                            // [slice][m] row sums of A
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(K, r0 + rows_per_block);
+    const int nq = N >> 2, slices = 256 / nq;
+    const int q = threadIdx.x % nq, sl = threadIdx.x / nq;
+    f32x4 acc[M];
+    float asum[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; asum[m] = 0.f; }
+    if (sl < slices) {
+        int r = r0 + sl;
+        for (; r + 7 * slices < r1; r += 8 * slices) {        // 8 rows in flight
+            f32x4 bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = *reinterpret_cast<const f32x4*>(B + (size_t)(r + u * slices) * ldb + q * 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                        const float am = A[(size_t)(r + u * slices) * lda + m];
+                        acc[m] += am * bv[u];
+                        asum[m] += am;
+                    }
+        }
+        for (; r < r1; r += slices) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(B + (size_t)r * ldb + q * 4);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                    const float am = A[(size_t)r * lda + m];
+                    acc[m] += am * bv;
+                    asum[m] += am;
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+                *reinterpret_cast<f32x4*>(red + ((size_t)sl * M + m) * N + q * 4) = acc[m];
+                if (q == 0) red_rs[sl][m] = asum[m];
+            }
+    }
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.x * M * N;
+    for (int i = threadIdx.x; i < M * nq; i += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(red + (size_t)i * 4);
+        for (int s2 = 1; s2 < slices; ++s2) v += *reinterpret_cast<const f32x4*>(red + (size_t)s2 * M * N + (size_t)i * 4);
+        *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
+    }
+    if (rs && threadIdx.x < M) {
+        float t = 0.f;
+        for (int s2 = 0; s2 < slices; ++s2) t += red_rs[s2][threadIdx.x];
+        rs[(size_t)blockIdx.x * M + threadIdx.x] = t;
+    }
+}
+
 // ---- live per-kernel timing (bench.py): hipEvents around each main-kernel launch, on the launch stream ----------
 struct ProfRec { int slot; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
@@ -629,6 +745,9 @@ extern "C" int vqh_gemm_profile_end(double* out) {
     return rc;
 }
 
+extern "C" int vqh_reduce_slabs(const float* slabs, int S, long long stride, long long n, float* out, float beta,
+                                hipStream_t stream);      // rowwise.hip
+
 static int g_gemm_flags = 1;
 extern "C" int vqh_gemm_set_flags(int flags) { const int old = g_gemm_flags; g_gemm_flags = flags; return old; }
 
@@ -667,6 +786,50 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
     g.rowsum_ws = nullptr;
     g.flags = g_gemm_flags;
     if (rowsum) VQH_CHECK_ARG(!a_kcontig && mode == EPI_LINEAR, "vqh_gemm_wgrad: row sums need the [K,M] A layout and a linear epilogue");
+
+    // skinny shapes (reconstruction heads): streaming kernels instead of a 97 % empty MFMA tile
+    if (!(g_gemm_flags & 64)) {
+        auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+        if (mode == EPI_LINEAR && !rowsum && a_kcontig && b_kcontig && N <= SK_MAX && K >= 64 && (K & 3) == 0 &&
+            (lda & 3) == 0 && (ldb & 3) == 0 && al16(A) && al16(B)) {
+            int blocks = (M + 3) / 4;
+            if (blocks > 2048) blocks = 2048;
+#define SK_CASE(V) case V: hipLaunchKernelGGL(skinny_n_kernel<V>, dim3(blocks), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, bias, beta, M, K); break
+            switch (N) { SK_CASE(1); SK_CASE(2); SK_CASE(3); SK_CASE(4); SK_CASE(5); SK_CASE(6); SK_CASE(7); default: SK_CASE(8); }
+#undef SK_CASE
+            VQH_LAUNCH_CHECK();
+            return VQH_OK;
+        }
+        if (mode == EPI_LINEAR && !rowsum && !bias && a_kcontig && !b_kcontig && K <= SK_MAX && K > 0 && N >= 64 &&
+            (N & 3) == 0 && (ldb & 3) == 0 && (ldc & 3) == 0 && al16(B) && al16(C)) {
+            const long long quads = (long long)M * (N >> 2);
+            int blocks = (int)((quads + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+#define SK_CASE(V) case V: hipLaunchKernelGGL(skinny_k_kernel<V>, dim3(blocks), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, beta, M, N); break
+            switch (K) { SK_CASE(1); SK_CASE(2); SK_CASE(3); SK_CASE(4); SK_CASE(5); SK_CASE(6); SK_CASE(7); default: SK_CASE(8); }
+#undef SK_CASE
+            VQH_LAUNCH_CHECK();
+            return VQH_OK;
+        }
+        if (mode == EPI_LINEAR && !a_kcontig && !b_kcontig && M <= SK_MAX && N >= 64 && (N & 3) == 0 && (ldb & 3) == 0 &&
+            (ldc & 3) == 0 && al16(B) && al16(C) && al16(workspace) && !bias && workspace && K >= 256 && N <= 1024 &&
+            256 % (N >> 2) == 0) {
+            const int rows_per_block = 64;
+            const int nblk = (K + rows_per_block - 1) / rows_per_block;
+            const long long per = (long long)M * N + (rowsum ? M : 0);
+            if ((long long)nblk * per <= workspace_floats && ldc == N) {
+                float* rs_ws = rowsum ? workspace + (size_t)nblk * M * N : nullptr;
+#define SK_CASE(V) case V: hipLaunchKernelGGL(skinny_m_kernel<V>, dim3(nblk), dim3(256), 0, stream, A, lda, B, ldb, workspace, rs_ws, N, K, rows_per_block); break
+                switch (M) { SK_CASE(1); SK_CASE(2); SK_CASE(3); SK_CASE(4); SK_CASE(5); SK_CASE(6); SK_CASE(7); default: SK_CASE(8); }
+#undef SK_CASE
+                VQH_LAUNCH_CHECK();
+                // many thin slabs: the slab-parallel reducer of rowwise.hip (16 slab lanes per column) instead of splitk_reduce
+                int rc2 = vqh_reduce_slabs(workspace, nblk, (long long)M * N, (long long)M * N, C, beta, stream);
+                if (rc2 == VQH_OK && rowsum) rc2 = vqh_reduce_slabs(rs_ws, nblk, (long long)M, (long long)M, rowsum, beta, stream);
+                return rc2;
+            }
+        }
+    }
 
     // split-K when the output has too few tiles to fill 256 CUs (weight gradients: K = B*L rows).
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);

@@ -44,7 +44,9 @@ def rel(a, b):
 # GEMM + epilogues
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("akc,bkc,M,N,K", [(1, 1, 257, 96, 130), (1, 0, 200, 64, 77), (0, 0, 64, 48, 1000),
-                                            (0, 1, 33, 65, 129), (1, 1, 1024, 512, 512), (1, 1, 111, 6, 64), (1, 1, 5, 3, 0)])
+                                            (0, 1, 33, 65, 129), (1, 1, 1024, 512, 512), (1, 1, 111, 6, 64), (1, 1, 5, 3, 0),
+                                            # skinny shapes (reconstruction heads): streaming kernels behind the same entry point
+                                            (1, 1, 1000, 3, 512), (1, 1, 257, 8, 64), (1, 0, 1000, 512, 3), (1, 0, 77, 64, 8)])
 def test_gemm_layouts(akc, bkc, M, N, K):
     L = _hip()
     torch.manual_seed(M + N + K)
@@ -56,6 +58,37 @@ def test_gemm_layouts(akc, bkc, M, N, K):
     L.gemm(akc, bkc, M, N, K, A, max(1, A.stride(0)), B, max(1, B.stride(0)), C, N, bias=bias, ws=ws)
     ref = (A if akc else A.t()).double() @ (B.t() if bkc else B).double() + bias.double()
     assert rel(C, ref) < 2e-6
+
+
+@pytest.mark.parametrize("rows,n_out,k_in", [(1000, 96, 130), (4096, 512, 256), (1000, 3, 512), (300, 6, 64), (16384, 3, 512)])
+def test_gemm_wgrad_weight_and_bias_gradients(rows, n_out, k_in):
+    """dW = dY^T X and db = column sums of dY in one entry point (split-K slabs, fused row sums, skinny outputs), with
+    and without accumulation into existing gradients."""
+    L = _hip()
+    torch.manual_seed(rows + n_out)
+    dY, X = torch.randn(rows, n_out, device=DEV), torch.randn(rows, k_in, device=DEV)
+    ws = torch.empty(1 << 23, device=DEV)
+    dW, db = torch.full((n_out, k_in), float("nan"), device=DEV), torch.full((n_out,), float("nan"), device=DEV)
+    L.call("vqh_gemm_wgrad", rows, n_out, k_in, dY, n_out, X, k_in, dW, k_in, db, 0.0, ws, ws.numel())
+    ref_w, ref_b = dY.double().t() @ X.double(), dY.double().sum(0)
+    assert rel(dW, ref_w) < 3e-6 and rel(db, ref_b) < 3e-6
+    L.call("vqh_gemm_wgrad", rows, n_out, k_in, dY, n_out, X, k_in, dW, k_in, db, 1.0, ws, ws.numel())     # accumulate
+    assert rel(dW, 2 * ref_w) < 3e-6 and rel(db, 2 * ref_b) < 3e-6
+    dW2 = torch.empty_like(dW)
+    L.call("vqh_gemm_wgrad", rows, n_out, k_in, dY, n_out, X, k_in, dW2, k_in, None, 0.0, ws, ws.numel())  # no bias grad
+    assert rel(dW2, ref_w) < 3e-6
+
+
+def test_gemm_accumulate_into_output():
+    """beta = 1 (second head's input gradient added to the first, decode_bwd) on the MFMA and the skinny path."""
+    L = _hip()
+    torch.manual_seed(5)
+    for M, N, K in ((500, 512, 3), (300, 256, 96)):
+        A, B = torch.randn(M, K, device=DEV), torch.randn(K, N, device=DEV)
+        C = torch.randn(M, N, device=DEV)
+        ref = C.double() + A.double() @ B.double()
+        L.gemm(1, 0, M, N, K, A, K, B, N, C, N, beta=1.0)
+        assert rel(C, ref) < 2e-6
 
 
 def test_gemm_epilogues_and_dropout_determinism():
