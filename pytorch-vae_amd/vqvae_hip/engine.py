@@ -166,12 +166,13 @@ class StepEngine:
 
     def lin_fwd(self, x, ldx, rows, W, b, out, ldo, mode=L.EPI_LINEAR, aux_in=None, aux_out=None, ldaux=0, site=0, p=0.0):
         N, K = W.shape
+        # the workspace lets small-row GEMMs (the batch-shared first-layer projections: 64 rows) split K over the chip
         L.gemm(1, 1, rows, N, K, x, ldx, W, K, out, ldo, bias=b, mode=mode, aux_in=aux_in, aux_out=aux_out, ldaux=ldaux,
-               rng=self.rng, site=site, p=p)
+               rng=self.rng, site=site, p=p, ws=self.ws)
 
     def lin_dgrad(self, dy, lddy, rows, W, dx, lddx, mode=L.EPI_LINEAR, aux_in=None, ldaux=0, beta=0.0, p=0.0):
         N, K = W.shape          # dx[rows,K] = dy[rows,N] . W[N,K]
-        L.gemm(1, 0, rows, K, N, dy, lddy, W, K, dx, lddx, mode=mode, aux_in=aux_in, ldaux=ldaux, beta=beta, p=p)
+        L.gemm(1, 0, rows, K, N, dy, lddy, W, K, dx, lddx, mode=mode, aux_in=aux_in, ldaux=ldaux, beta=beta, p=p, ws=self.ws)
 
     def lin_wgrad(self, dy, lddy, x, ldx, rows, gW, gb):
         N, K = gW.shape         # gW[N,K] = dy[rows,N]^T . x[rows,K] ; gb[N] = column sums of dy (same launch)
