@@ -69,16 +69,56 @@ __device__ __forceinline__ float attn_keep(const DropCfg& d, unsigned rowkey, in
 // for the key-side kernel) is staged 64 rows at a time into LDS with coalesced 16-byte loads issued in bulk,
 // then every MFMA fragment comes from LDS:  [row][DH+4] floats (row stride == 4 mod 64 dwords: the 16-lane
 // groups of ds_read_b128 cover all 64 banks; the transposed operand reads 32 consecutive dwords per half).
+// Loads are issued as one batch per thread, branch-free: rows beyond the end are read from the last valid row (clamped
+// address) and zeroed by a select.  With a guard around each load the compiler emitted one load -> s_waitcnt -> LDS store
+// round trip per row group, i.e. 4-8 serial memory latencies in front of every tile.
+template <int DH, int NT>
+struct RowBatch {
+    static constexpr int C4 = DH / 4, N = (64 * C4 + NT - 1) / NT;
+    f32x4 v[N];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int row0, int nrows_total, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int i = tid + j * NT, r = row0 + i / C4, c = (i % C4) * 4;
+            const int rr = max(min(r, nrows_total - 1), 0);
+            v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)rr * ld + c);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int i = tid + j * NT, r = row0 + i / C4;
+            const bool in = (r < nrows_total) && (i < 64 * C4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = in ? v[j][e] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ dst, int tid) const {
+        constexpr int LD = DH + 4;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int i = tid + j * NT, r = i / C4, c = (i % C4) * 4;
+            if (i < 64 * C4) *reinterpret_cast<f32x4*>(dst + r * LD + c) = v[j];
+        }
+    }
+};
+
 template <int DH, int NT>
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int ld, int row0,
                                            int nrows_total, int tid) {
-    constexpr int LD = DH + 4, C4 = DH / 4;
-    for (int i = tid; i < 64 * C4; i += NT) {
-        const int r = i / C4, c = (i % C4) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row0 + r < nrows_total) v = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + r) * ld + c);
-        *reinterpret_cast<f32x4*>(dst + r * LD + c) = v;
-    }
+    RowBatch<DH, NT> b;
+    b.load(src, ld, row0, nrows_total, tid);
+    b.store(dst, tid);
+}
+
+// two operands with the same row range (K and V, Q and dO): both batches in flight before the first LDS store
+template <int DH, int NT>
+__device__ __forceinline__ void stage_rows2(float* __restrict__ dst0, const float* __restrict__ src0, int ld0,
+                                            float* __restrict__ dst1, const float* __restrict__ src1, int ld1, int row0,
+                                            int nrows_total, int tid) {
+    RowBatch<DH, NT> b0, b1;
+    b0.load(src0, ld0, row0, nrows_total, tid);
+    b1.load(src1, ld1, row0, nrows_total, tid);
+    b0.store(dst0, tid);
+    b1.store(dst1, tid);
 }
 
 template <int DH, int NW>
@@ -88,7 +128,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) 
     // registers before the current one is consumed and stored behind it, one barrier per chunk instead of two.
     extern __shared__ __attribute__((aligned(16))) float kv_smem[];
     constexpr bool PF = (NW == 4);
-    constexpr int NPT = (64 * (DH / 4)) / (64 * NW), C4 = DH / 4;
 #define KST(s_) (kv_smem + (s_) * 2 * 64 * LD)
 #define VST(s_) (kv_smem + (s_) * 2 * 64 * LD + 64 * LD)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -116,24 +155,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) 
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m = -INFINITY, lsum = 0.f;
 
-    f32x4 kreg[PF ? NPT : 1], vreg[PF ? NPT : 1];
+    RowBatch<DH, 64 * NW> kreg, vreg;
     auto gload = [&](int c0) {
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const bool in = c0 + r < a.S;
-            kreg[j] = in ? *reinterpret_cast<const f32x4*>(Kb + (size_t)(c0 + r) * a.ldk + c) : z;
-            vreg[j] = in ? *reinterpret_cast<const f32x4*>(Vb + (size_t)(c0 + r) * a.ldv + c) : z;
-        }
+        kreg.load(Kb, a.ldk, c0, a.S, tid);
+        vreg.load(Vb, a.ldv, c0, a.S, tid);
     };
     auto lstore = [&](float* Kd, float* Vd) {
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
-            *reinterpret_cast<f32x4*>(Kd + r * LD + c) = kreg[j];
-            *reinterpret_cast<f32x4*>(Vd + r * LD + c) = vreg[j];
-        }
+        kreg.store(Kd, tid);
+        vreg.store(Vd, tid);
     };
     if (PF) {
         gload(0);
@@ -150,8 +179,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const AttnArgs a) 
             if (more) gload(c0 + 64);
         } else {
             __syncthreads();
-            stage_rows<DH, 64 * NW>(KST(0), Kb, a.ldk, c0, a.S, tid);
-            stage_rows<DH, 64 * NW>(VST(0), Vb, a.ldv, c0, a.S, tid);
+            stage_rows2<DH, 64 * NW>(KST(0), Kb, a.ldk, VST(0), Vb, a.ldv, c0, a.S, tid);
             __syncthreads();
         }
         if (active) {
@@ -245,7 +273,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs 
     // registers before the current one is consumed and stored behind it, one barrier per chunk instead of two.
     extern __shared__ __attribute__((aligned(16))) float kv_smem[];
     constexpr bool PF = (NW == 4);
-    constexpr int NPT = (64 * (DH / 4)) / (64 * NW), C4 = DH / 4;
 #define KST(s_) (kv_smem + (s_) * 2 * 64 * LD)
 #define VST(s_) (kv_smem + (s_) * 2 * 64 * LD + 64 * LD)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -283,24 +310,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-    f32x4 kreg[PF ? NPT : 1], vreg[PF ? NPT : 1];
+    RowBatch<DH, 64 * NW> kreg, vreg;
     auto gload = [&](int c0) {
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const bool in = c0 + r < a.S;
-            kreg[j] = in ? *reinterpret_cast<const f32x4*>(Kb + (size_t)(c0 + r) * a.ldk + c) : z;
-            vreg[j] = in ? *reinterpret_cast<const f32x4*>(Vb + (size_t)(c0 + r) * a.ldv + c) : z;
-        }
+        kreg.load(Kb, a.ldk, c0, a.S, tid);
+        vreg.load(Vb, a.ldv, c0, a.S, tid);
     };
     auto lstore = [&](float* Kd, float* Vd) {
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const int i = tid + j * 64 * NW, r = i / C4, c = (i % C4) * 4;
-            *reinterpret_cast<f32x4*>(Kd + r * LD + c) = kreg[j];
-            *reinterpret_cast<f32x4*>(Vd + r * LD + c) = vreg[j];
-        }
+        kreg.store(Kd, tid);
+        vreg.store(Vd, tid);
     };
     if (PF) {
         gload(0);
@@ -317,8 +334,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnArgs 
             if (more) gload(c0 + 64);
         } else {
             __syncthreads();
-            stage_rows<DH, 64 * NW>(KST(0), Kb, a.ldk, c0, a.S, tid);
-            stage_rows<DH, 64 * NW>(VST(0), Vb, a.ldv, c0, a.S, tid);
+            stage_rows2<DH, 64 * NW>(KST(0), Kb, a.ldk, VST(0), Vb, a.ldv, c0, a.S, tid);
             __syncthreads();
         }
         if (active) {
@@ -421,7 +437,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnArgs
     const size_t rowbase = ((size_t)b * a.nh + hh) * a.T;
     for (int c0 = 0; c0 < a.T; c0 += 64) {
         __syncthreads();
-        stage_rows<DH, 64 * NW>(Qs, Qb, a.ldq, c0, a.T, tid);
+        stage_rows<DH, 64 * NW>(Qs, Qb, a.ldq, c0, a.T, tid);          // one batch at a time: this kernel has no registers to spare
         stage_rows<DH, 64 * NW>(Os, dOb, a.lddo, c0, a.T, tid);
         if (tid < 64) {
             const int qq = c0 + tid;
@@ -522,19 +538,14 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_small_kernel(const AttnArgs a
     const size_t rowbase = ((size_t)b * a.nh + hh) * a.T;
     unsigned long long seed = 0, step = 0;
     if (a.drop.p > 0.f) { seed = a.drop.rng_state[0]; step = a.drop.rng_state[1]; }
-#pragma unroll
-    for (int i = tid; i < 64 * C4; i += 128) {
-        const int r = i / C4, c = (i % C4) * 4;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 qv = z, kk = z, vv = z;
-        if (r < a.T) qv = *reinterpret_cast<const f32x4*>(Qb + (size_t)r * a.ldq + c);
-        if (r < a.S) {
-            kk = *reinterpret_cast<const f32x4*>(Kb + (size_t)r * a.ldk + c);
-            vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)r * a.ldv + c);
-        }
-        *reinterpret_cast<f32x4*>(Qs + r * LD + c) = qv;
-        *reinterpret_cast<f32x4*>(Ks + r * LD + c) = kk;
-        *reinterpret_cast<f32x4*>(Vs + r * LD + c) = vv;
+    {
+        RowBatch<DH, 128> bq, bk, bv;          // 24 loads per lane in flight, one wait
+        bq.load(Qb, a.ldq, 0, a.T, tid);
+        bk.load(Kb, a.ldk, 0, a.S, tid);
+        bv.load(Vb, a.ldv, 0, a.S, tid);
+        bq.store(Qs, tid);
+        bk.store(Ks, tid);
+        bv.store(Vs, tid);
     }
     __syncthreads();
     const int q = wave * 32 + l31;
@@ -551,64 +562,70 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_small_kernel(const AttnArgs a
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-        float m = -INFINITY, lsum = 0.f;
+        // All S <= 64 keys are in LDS: one softmax pass (no running-max rescale), and both 32-key score tiles in flight as
+        // independent MFMA chains so the exp / dropout VALU of one can issue under the MFMAs of the other.
+        f32x16 sacc[2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int s0 = sub * 32;
-            if (s0 >= a.S) break;
-            f32x16 sacc;
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-            const float* kr = Ks + (s0 + l31) * LD + 4 * h;
-            f32x4 kfr[NG];
+            for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+        {
+            f32x4 kfr[2][NG];
 #pragma unroll
-            for (int t = 0; t < NG; ++t) kfr[t] = *reinterpret_cast<const f32x4*>(kr + 8 * t);
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int t = 0; t < NG; ++t)
+                    kfr[sub][t] = *reinterpret_cast<const f32x4*>(Ks + (sub * 32 + l31) * LD + 4 * h + 8 * t);
 #pragma unroll
             for (int t = 0; t < NG; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[t][j], qf[t][j], sacc, 0, 0, 0);
-            const int keyl = s0 + l31;
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+                        sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[sub][t][j], qf[t][j], sacc[sub], 0, 0, 0);
+        }
+        unsigned int vmask[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int keyl = sub * 32 + l31;
             const unsigned char vb = (kv && keyl < a.S) ? kv[keyl] : (unsigned char)1;
-            const unsigned int vmask = (unsigned int)__ballot((keyl < a.S) && vb != 0);
-            float mx = -INFINITY;
-            bool ok[16];
+            vmask[sub] = (unsigned int)__ballot((keyl < a.S) && vb != 0);      // keys beyond S (zero rows in LDS) are masked
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = ((vmask[sub] >> kmap(r, h)) & 1u) ? fmaxf(m, sacc[sub][r]) : m;
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float p[2][16];
+        float lsum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                ok[r] = (vmask >> kmap(r, h)) & 1u;
-                mx = ok[r] ? fmaxf(mx, sacc[r]) : mx;
+                p[sub][r] = ((vmask[sub] >> kmap(r, h)) & 1u) ? __expf(sacc[sub][r] - m) : 0.f;
+                lsum += p[sub][r];
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx);
-            const float corr = (m_new == -INFINITY) ? 1.f : __expf(m - m_new);
-            float psum = 0.f;
-            float p[16];
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (a.drop.p > 0.f) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = ok[r] ? __expf(sacc[r] - m_new) : 0.f;
-                psum += p[r];
-            }
-            psum += __shfl_xor(psum, 32, 64);
-            lsum = lsum * corr + psum;
-            m = m_new;
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int d = 0; d < ND; ++d)
+                for (int r = 0; r < 16; ++r) p[sub][r] *= attn_keep(a.drop, rowkey, sub * 32 + kmap(r, h));
+        }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= corr;
-            if (a.drop.p > 0.f) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] *= attn_keep(a.drop, rowkey, s0 + kmap(r, h));
-            }
+        for (int sub = 0; sub < 2; ++sub) {
             float vv[ND][16];
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const int dcol = d * 32 + l31;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) vv[d][r] = (dcol < DH) ? Vs[(s0 + kmap(r, h)) * LD + dcol] : 0.f;
+                for (int r = 0; r < 16; ++r) vv[d][r] = (dcol < DH) ? Vs[(sub * 32 + kmap(r, h)) * LD + dcol] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[d][r], p[r], o[d], 0, 0, 0);
+                for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[d][r], p[sub][r], o[d], 0, 0, 0);
         }
         // O^T accumulator -> this wave's own rows of Qs (only this wave read them, and only into qf above)
         const float inv = 1.f / lsum;
@@ -664,29 +681,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnArgs a
     unsigned long long seed = 0, step = 0;
     if (a.drop.p > 0.f) { seed = a.drop.rng_state[0]; step = a.drop.rng_state[1]; }
 
-    // ---- stage operands (rows beyond T / S are zero) and reduce D
+    // ---- stage operands (rows beyond T / S are zero) and reduce D: 20 loads per lane in flight, one wait
+    {
+        RowBatch<DH, 256> bq, bdo, bo, bk, bv;
+        bq.load(Qb, a.ldq, 0, a.T, tid);
+        bdo.load(dOb, a.lddo, 0, a.T, tid);
+        bo.load(Ob, a.ldo, 0, a.T, tid);
+        bk.load(Kb, a.ldk, 0, a.S, tid);
+        bv.load(Vb, a.ldv, 0, a.S, tid);
+        bq.store(Qs, tid);
+        bk.store(Ks, tid);
+        bv.store(Vs, tid);
+        bdo.store(Os, tid);
 #pragma unroll
-    for (int i = tid; i < 64 * C4; i += 256) {
-        const int r = i / C4, c = (i % C4) * 4;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 qv = z, kk = z, vv = z, dov = z, ov = z;
-        if (r < a.T) {
-            qv = *reinterpret_cast<const f32x4*>(Qb + (size_t)r * a.ldq + c);
-            dov = *reinterpret_cast<const f32x4*>(dOb + (size_t)r * a.lddo + c);
-            ov = *reinterpret_cast<const f32x4*>(Ob + (size_t)r * a.ldo + c);
-        }
-        if (r < a.S) {
-            kk = *reinterpret_cast<const f32x4*>(Kb + (size_t)r * a.ldk + c);
-            vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)r * a.ldv + c);
-        }
-        *reinterpret_cast<f32x4*>(Qs + r * LD + c) = qv;
-        *reinterpret_cast<f32x4*>(Ks + r * LD + c) = kk;
-        *reinterpret_cast<f32x4*>(Vs + r * LD + c) = vv;
-        *reinterpret_cast<f32x4*>(Os + r * LD + c) = dov;
-        float dsum = dov[0] * ov[0] + dov[1] * ov[1] + dov[2] * ov[2] + dov[3] * ov[3];
+        for (int j = 0; j < RowBatch<DH, 256>::N; ++j) {
+            const int i = tid + j * 256, r = i / C4;
+            float dsum = bdo.v[j][0] * bo.v[j][0] + bdo.v[j][1] * bo.v[j][1] + bdo.v[j][2] * bo.v[j][2] + bdo.v[j][3] * bo.v[j][3];
 #pragma unroll
-        for (int off = C4 / 2; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
-        if ((i % C4) == 0) Ds[r] = dsum;
+            for (int off = C4 / 2; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+            if ((i % C4) == 0 && i < 64 * C4) Ds[r] = dsum;
+        }
     }
     if (tid < 64) {
         Ls[tid] = (tid < a.T) ? a.LSE[rowbase + tid] : 0.f;
@@ -907,6 +921,7 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     VQH_CHECK_ARG(B >= 0 && nh > 0 && T >= 0 && S >= 0, "vqh_attn_fwd: bad shape");
     VQH_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "vqh_attn_fwd: head dim must be 16/32/64");
     if (B == 0 || T == 0) return VQH_OK;
+    VQH_CHECK_ARG(S > 0, "vqh_attn_fwd: no keys");
     VQH_CHECK_ARG(Q && K && V && O, "vqh_attn_fwd: null pointer");
     VQH_CHECK_ARG(aligned16(Q, ldq) && aligned16(K, ldk) && aligned16(V, ldv), "vqh_attn_fwd: operands must be 16-byte aligned");
     VQH_CHECK_ARG(drop_p == 0.f || rng_state, "vqh_attn_fwd: dropout needs rng_state");

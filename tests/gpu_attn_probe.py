@@ -31,3 +31,14 @@ for p, m in ((0.0, None), (0.0, mask), (0.1, mask)):
     flops = 4.0 * B * nh * T * S * dh
     tf, tb = t(f), t(b)
     print(f"p={p} mask={'yes' if m is not None else 'no'}: fwd {tf:7.1f} us ({flops/tf/1e6:5.1f} TF)  bwd(dq+dkv) {tb:7.1f} us ({2.5*flops/tb/1e6:5.1f} TF)", flush=True)
+
+# layout experiment: the same 2048 (batch, head) problems with every operand tile contiguous (nh = 1, ld = dh)
+B2 = B * nh
+q2, k2, v2 = (torch.randn(B2 * T, dh, device=dev) for _ in range(3))
+o2, do2 = torch.empty(B2 * T, dh, device=dev), torch.randn(B2 * T, dh, device=dev)
+lse2, dsum2 = torch.empty(B2 * T, device=dev), torch.empty(B2 * T, device=dev)
+dq2, dk2, dv2 = (torch.empty(B2 * T, dh, device=dev) for _ in range(3))
+f = lambda: L.call("vqh_attn_fwd", q2, dh, k2, dh, v2, dh, o2, dh, lse2, None, B2, 1, T, S, dh, 0, rng, 1, 0.1)
+b = lambda: L.call("vqh_attn_bwd", q2, dh, k2, dh, v2, dh, o2, dh, lse2, do2, dh, dsum2, dq2, dh, dk2, dh, dv2, dh, None,
+                   B2, 1, T, S, dh, 0, rng, 1, 0.1)
+print(f"contiguous tiles (nh=1, B={B2}): fwd {t(f):7.1f} us   bwd {t(b):7.1f} us", flush=True)
