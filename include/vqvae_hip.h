@@ -75,9 +75,12 @@ int vqh_gemm_profile_end(double* out);
 /* nn.LayerNorm forward/backward (eps 1e-5, biased variance); 35 instances on the path */
 int vqh_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, float* mean,
                       float* rstd, int rows, int H, float eps, vqh_stream_t stream);
+/* dx_drop (optional, [rows,H] dense): also writes dx * keep-mask(drop_site) -- the dropout backward of the residual
+ * branch that consumes dx next (dropout1/dropout2 of the Transformer layers), folded into the producing kernel */
 int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
                       const float* rstd, float* dx, int lddx, int accumulate_dx, float* dw, float* db, float beta,
-                      int rows, int H, float* workspace, long long workspace_floats, vqh_stream_t stream);
+                      int rows, int H, float* dx_drop, const unsigned long long* rng_state, unsigned drop_site,
+                      float drop_p, float* workspace, long long workspace_floats, vqh_stream_t stream);
 
 /* out[i] = beta*out[i] + sum_s slabs[s*stride + i] ;  out[n] = beta*out[n] + sum_m X[m][n] */
 int vqh_reduce_slabs(const float* slabs, int S, long long stride, long long n, float* out, float beta,

@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, float* __restrict__ dx,
                                                                 int lddx, int accumulate, float* __restrict__ part,
-                                                                int rows, int H) {
+                                                                int rows, int H, float* __restrict__ dx_drop, DropCfg drop) {
+    // dx_drop (optional, [rows, H] contiguous): the final dx times the keep mask of the dropout site that consumes it
+    // next in backward -- the residual-stream gradient is written once more here instead of being re-read by a
+    // separate dropout-backward pass
+    const unsigned dkey = dx_drop ? drop_key(drop, drop.rng_state[0], drop.rng_state[1]) : 0u;
     __shared__ float red[WAVES_PER_BLOCK][2][256 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = H >> 2;
@@ -166,6 +170,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                 f32x4 v = (g[j] - s1 - xh[j] * s2) * rs;
                 if (accumulate) v += *reinterpret_cast<const f32x4*>(dxr + 4 * q);
                 *reinterpret_cast<f32x4*>(dxr + 4 * q) = v;
+                if (dx_drop) {
+                    float f[4];
+                    drop4(drop, dkey, ((unsigned long long)row * H + 4 * q) >> 2, f);
+                    v[0] *= f[0]; v[1] *= f[1]; v[2] *= f[2]; v[3] *= f[3];
+                    *reinterpret_cast<f32x4*>(dx_drop + (size_t)row * H + 4 * q) = v;
+                }
             }
         }
     }
@@ -522,20 +532,23 @@ extern "C" int vqh_reduce_slabs(const float* slabs, int S, long long stride, lon
 // dw/db are written as beta*old + sum (beta=0 overwrite).  workspace >= 2*H*nblocks floats.
 extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* w,
                                  const float* mean, const float* rstd, float* dx, int lddx, int accumulate_dx,
-                                 float* dw, float* db, float beta, int rows, int H, float* workspace,
+                                 float* dw, float* db, float beta, int rows, int H, float* dx_drop,
+                                 const unsigned long long* rng_state, unsigned drop_site, float drop_p, float* workspace,
                                  long long workspace_floats, hipStream_t stream) {
     VQH_CHECK_ARG(rows >= 0 && H > 0 && H <= 2048, "vqh_layernorm_bwd: H must be in [1,2048]");
     if (rows == 0) return VQH_OK;
     VQH_CHECK_ARG(dy && x && w && mean && rstd && dx && dw && db && workspace, "vqh_layernorm_bwd: null pointer");
+    VQH_CHECK_ARG(!dx_drop || (rng_state && drop_p > 0.f && drop_p < 1.f), "vqh_layernorm_bwd: dx_drop needs rng_state and 0 < p < 1");
     int nblk = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (nblk > 1024) nblk = 1024;
     VQH_CHECK_ARG((long long)nblk * 2 * H <= workspace_floats, "vqh_layernorm_bwd: workspace too small");
     const bool vec = (H % 4 == 0) && H <= 1024 && ((lddy | ldx | lddx) % 4 == 0) &&
                      (((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
-                        reinterpret_cast<uintptr_t>(w)) & 15) == 0);
+                        reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dx_drop)) & 15) == 0);
+    const DropCfg dcfg = dx_drop ? make_drop(rng_state, drop_site, drop_p) : DropCfg{};
 #define LN_BWD_V(V)                                                                                                    \
     hipLaunchKernelGGL((layernorm_bwd_vec_kernel<V>), dim3(nblk), dim3(256), 0, stream, dy, lddy, x, ldx, w, mean, rstd, \
-                       dx, lddx, accumulate_dx, workspace, rows, H)
+                       dx, lddx, accumulate_dx, workspace, rows, H, dx_drop, dcfg)
     if (vec) {
         if (H <= 256) LN_BWD_V(1);
         else if (H <= 512) LN_BWD_V(2);
@@ -553,6 +566,11 @@ extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int 
 #undef LN_BWD
 #undef LN_BWD_V
     VQH_LAUNCH_CHECK();
+    if (dx_drop && !vec) {        // scalar kernel: the mask is applied by the stand-alone pass (needs a dense dx)
+        VQH_CHECK_ARG(lddx == H, "vqh_layernorm_bwd: dx_drop on the unaligned path needs a dense dx");
+        hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks_for(((long long)rows * H + 3) / 4)), dim3(256), 0, stream, dx, dx_drop,
+                           (long long)rows * H, dcfg);
+    }
     // slab layout [blk][2][H]: dw = sum_blk slab[blk][0], db = sum_blk slab[blk][1]  (one launch for both)
     hipLaunchKernelGGL(reduce_slabs2_kernel, dim3((2 * H + 63) / 64), dim3(1024), 0, stream, workspace, nblk, H, dw, db, beta);
     VQH_LAUNCH_CHECK();

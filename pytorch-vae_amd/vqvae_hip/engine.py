@@ -86,6 +86,8 @@ class StepEngine:
         self.defer_ema = False
         # first decoder / tokenizer layer: project the batch-invariant queries once instead of per sample
         self.share_layer0 = os.environ.get("VQH_SHARE_LAYER0", "1") != "0"
+        # dropout backward of a residual branch written by the LayerNorm backward that produces its input (ln_bwd emit)
+        self.fold_dropout_bwd = True
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -159,10 +161,17 @@ class StepEngine:
              self.H, LN_EPS)
         return mean, rstd
 
-    def ln_bwd(self, name, dy, lddy, x, ldx, tag, dx, lddx, accumulate, rows):
+    def ln_bwd(self, name, dy, lddy, x, ldx, tag, dx, lddx, accumulate, rows, emit=None):
+        """emit = (site, p, buffer tag): also write dx * keep-mask(site) -- the dropout backward of the block that consumes
+        dx next -- and return that buffer (None when dropout is off)."""
+        dxd, site, p = None, 0, 0.0
+        if emit is not None and emit[1] > 0.0 and self.fold_dropout_bwd:
+            site, p = emit[0], emit[1]
+            dxd = self.T(emit[2], rows * self.H)
         call("vqh_layernorm_bwd", dy, lddy, x, ldx, self.P[name + ".weight"], self.buf[tag + ".mean"],
              self.buf[tag + ".rstd"], dx, lddx, int(accumulate), self.G[name + ".weight"], self.G[name + ".bias"], 0.0,
-             rows, self.H, self.ws, self.ws.numel())
+             rows, self.H, dxd, self.rng if dxd is not None else None, site, p, self.ws, self.ws.numel())
+        return dxd
 
     def lin_fwd(self, x, ldx, rows, W, b, out, ldo, mode=L.EPI_LINEAR, aux_in=None, aux_out=None, ldaux=0, site=0, p=0.0):
         N, K = W.shape
@@ -266,7 +275,7 @@ class StepEngine:
         return x1
 
     def attn_block_bwd(self, pre, attn, norm, x0, dres, rows, B, T, nh, kvalid, mem=None, rows_kv=None, S=None,
-                       d_mem=None, mem_beta=0.0, p=0.1, shared=False):
+                       d_mem=None, mem_beta=0.0, p=0.1, shared=False, dy_in=None, emit=None):
         """dres holds d x1 on entry and d x0 on exit (in place).
         shared: dres keeps only the residual branch; the LayerNorm branch's gradient, already summed over the batch
         (LayerNorm backward is linear in dy for fixed x), is returned as a [T, H] buffer for the caller to add to the
@@ -275,7 +284,8 @@ class StepEngine:
         a = f"{pre}.{attn}"
         self_attn = mem is None
         h = self.buf[f"{pre}.{norm}.y"]
-        dy = self.drop_bwd(dres, rows * H, self.site(a + ".drop"), self.pdrop(p), "tmp.dy")
+        # dy_in: dres * mask already written by the LayerNorm backward that produced dres (ln_bwd emit)
+        dy = dy_in if dy_in is not None else self.drop_bwd(dres, rows * H, self.site(a + ".drop"), self.pdrop(p), "tmp.dy")
         self.lin_wgrad(dy, H, self.buf[a + ".ao"], H, rows, self.G[a + ".out_proj.weight"], self.G[a + ".out_proj.bias"])
         d_ao = self.T("tmp.dao", rows, H)
         self.lin_dgrad(dy, H, rows, self.P[a + ".out_proj.weight"], d_ao, H)
@@ -286,8 +296,7 @@ class StepEngine:
             dx_sh = self.T(f"{pre}.{norm}.dx_sh", T, H)
             self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dx_sh, H, False, T)
             return dx_sh
-        self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dres, H, True, rows)
-        return None
+        return self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dres, H, True, rows, emit=emit)
 
     def ffn_block_fwd(self, pre, norm, lin1, lin2, x0, rows, act, p_inner, p_out):
         """x1 = x0 + dropout(lin2(dropout(act(lin1(LN(x0))))))   act: 'relu' (encoder/decoder) or 'gelu' (tokenizer)"""
@@ -308,13 +317,14 @@ class StepEngine:
                      mode=L.EPI_DROP_RESID, aux_in=x0, ldaux=H, site=self.site(f"{pre}.{lin2}.drop"), p=self.pdrop(p_out))
         return x1
 
-    def ffn_block_bwd(self, pre, norm, lin1, lin2, x0, dres, rows, act, p_inner, p_out):
+    def ffn_block_bwd(self, pre, norm, lin1, lin2, x0, dres, rows, act, p_inner, p_out, dy_in=None, emit=None):
         H = self.H
         W1, W2 = self.P[f"{pre}.{lin1}.weight"], self.P[f"{pre}.{lin2}.weight"]
         F = W1.shape[0]
         f1 = self.buf[f"{pre}.{lin1}.y"]
         h = self.buf[f"{pre}.{norm}.y"]
-        dy = self.drop_bwd(dres, rows * H, self.site(f"{pre}.{lin2}.drop"), self.pdrop(p_out), "tmp.dy")
+        dy = dy_in if dy_in is not None else self.drop_bwd(dres, rows * H, self.site(f"{pre}.{lin2}.drop"), self.pdrop(p_out),
+                                                           "tmp.dy")
         self.lin_wgrad(dy, H, f1, F, rows, self.G[f"{pre}.{lin2}.weight"], self.G[f"{pre}.{lin2}.bias"])
         if act == "relu":
             # d pre-activation, written over the saved post-activation (read-then-write per element)
@@ -326,7 +336,7 @@ class StepEngine:
         self.lin_wgrad(dpre, F, h, H, rows, self.G[f"{pre}.{lin1}.weight"], self.G[f"{pre}.{lin1}.bias"])
         dh = self.T("tmp.dh", rows, H)
         self.lin_dgrad(dpre, F, rows, W1, dh, H)
-        self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dres, H, True, rows)
+        return self.ln_bwd(f"{pre}.{norm}", dh, H, x0, H, f"{pre}.{norm}", dres, H, True, rows, emit=emit)
 
     # ------------------------------------------------------------------ model sections
     def encode(self, x, mask):
@@ -394,12 +404,23 @@ class StepEngine:
         xs = c["ss_xs"]
         dres = self.T("tmp.dres_seq", ML, H)
         self.ln_bwd("ln_ss", dcat[:, H:], 2 * H, xs[-1], H, "ln_ss", dres, H, False, ML)
-        for i in reversed(range(SS_LAYERS)):
-            pre = f"ss_encoder.layers.{i}"
-            self.ffn_block_bwd(pre, "norm2", "linear1", "linear2", xs[2 * i + 1], dres, ML, "relu", 0.1, 0.1)
-            self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask)
+        self._encoder_stack_bwd("ss_encoder", SS_LAYERS, xs, dres, ML, B, Lq, mask)
         call("vqh_embed_bwd", dres, c["x"], 6, 3, self.G["ss_input_proj.weight"], self.G["ss_input_proj.bias"], 0.0, ML, H,
              self.rng, 0, 0.0, self.ws, self.ws.numel())
+
+    def _encoder_stack_bwd(self, stack, n_layers, xs, dres, ML, B, Lq, mask):
+        """Backward through n_layers pre-LN encoder layers.  Every block ends in a LayerNorm backward that accumulates into
+        dres; it also emits dres * mask of the dropout site that opens the NEXT block (in backward order), so only the
+        first block of the stack runs the stand-alone dropout-backward pass."""
+        dy = None
+        for i in reversed(range(n_layers)):
+            pre = f"{stack}.layers.{i}"
+            dy = self.ffn_block_bwd(pre, "norm2", "linear1", "linear2", xs[2 * i + 1], dres, ML, "relu", 0.1, 0.1, dy_in=dy,
+                                    emit=(self.site(f"{pre}.self_attn.drop"), self.pdrop(0.1), "tmp.dy"))
+            nxt = None
+            if i > 0:
+                nxt = (self.site(f"{stack}.layers.{i - 1}.linear2.drop"), self.pdrop(0.1), "tmp.dy")
+            dy = self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask, dy_in=dy, emit=nxt)
 
     def encode_bwd_geo(self):
         c = self.ctx
@@ -410,10 +431,7 @@ class StepEngine:
         dhg = self.T("tmp.dh", ML, H)
         self.ln_bwd("ln_geo", dcat, 2 * H, self.buf["enc_ln.y"], H, "ln_geo", dhg, H, False, ML)
         self.ln_bwd("enc_ln", dhg, H, xs[-1], H, "enc_ln", dres, H, False, ML)
-        for i in reversed(range(self.m.num_layers)):
-            pre = f"encoder.layers.{i}"
-            self.ffn_block_bwd(pre, "norm2", "linear1", "linear2", xs[2 * i + 1], dres, ML, "relu", 0.1, 0.1)
-            self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask)
+        self._encoder_stack_bwd("encoder", self.m.num_layers, xs, dres, ML, B, Lq, mask)
         call("vqh_embed_bwd", dres, c["x"], 6, 0, self.G["input_proj.weight"], self.G["input_proj.bias"], 0.0, ML, H,
              self.rng, self.site("inp_dropout"), self.pdrop(0.1), self.ws, self.ws.numel())
 
@@ -671,13 +689,22 @@ class StepEngine:
         mem = self.buf["dec.mem"]
         d_mem = self.T("tmp.d_mem", MN, H)
         nl = self.m.num_layers
+        dy, dx_sh, pd = None, None, self.pdrop(0.1)
         for i in reversed(range(nl)):
             pre = f"decoder.layers.{i}"
-            self.ffn_block_bwd(pre, "norm3", "linear1", "linear2", xs[3 * i + 2], dres, ML, "relu", 0.1, 0.1)
-            self.attn_block_bwd(pre, "multihead_attn", "norm2", xs[3 * i + 1], dres, ML, B, Lq, self.nh, None, mem=mem,
-                                rows_kv=MN, S=Nmem, d_mem=d_mem, mem_beta=0.0 if i == nl - 1 else 1.0)
-            dx_sh = self.attn_block_bwd(pre, "self_attn", "norm1", xs[3 * i], dres, ML, B, Lq, self.nh, mask,
-                                        shared=self.share_layer0 and i == 0)
+            dy = self.ffn_block_bwd(pre, "norm3", "linear1", "linear2", xs[3 * i + 2], dres, ML, "relu", 0.1, 0.1, dy_in=dy,
+                                    emit=(self.site(f"{pre}.multihead_attn.drop"), pd, "tmp.dy"))
+            dy = self.attn_block_bwd(pre, "multihead_attn", "norm2", xs[3 * i + 1], dres, ML, B, Lq, self.nh, None, mem=mem,
+                                     rows_kv=MN, S=Nmem, d_mem=d_mem, mem_beta=0.0 if i == nl - 1 else 1.0, dy_in=dy,
+                                     emit=(self.site(f"{pre}.self_attn.drop"), pd, "tmp.dy"))
+            sh0 = self.share_layer0 and i == 0
+            nxt = (self.site(f"decoder.layers.{i - 1}.linear2.drop"), pd, "tmp.dy") if i > 0 else None
+            out = self.attn_block_bwd(pre, "self_attn", "norm1", xs[3 * i], dres, ML, B, Lq, self.nh, mask, shared=sh0,
+                                      dy_in=dy, emit=None if sh0 else nxt)
+            if sh0:
+                dx_sh, dy = out, None
+            else:
+                dy = out
         # tgt = query_embed[:L] + pos_enc[:L] broadcast over the batch
         gq = self.G["query_embed.weight"]
         call("vqh_memset", gq, 0, gq.numel() * 4)

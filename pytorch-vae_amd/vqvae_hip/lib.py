@@ -25,7 +25,7 @@ _PROTOS = {
     "vqh_gemm": "iiiiipipipipippifpufplp",
     "vqh_gemm_wgrad": "iiipipipipfplp",
     "vqh_layernorm_fwd": "pipppippiifp",
-    "vqh_layernorm_bwd": "pipippppiippfiiplp",
+    "vqh_layernorm_bwd": "pipippppiippfiippufplp",
     "vqh_reduce_slabs": "pillpfp",
     "vqh_colsum": "piiipfplp",
     "vqh_embed_fwd": "piippppiiipufp",

@@ -142,8 +142,16 @@ def test_layernorm_forward_backward():
         assert rel(y, yr) < 2e-6
         dx, dw, db = torch.ones_like(x), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
         ws = torch.empty(1 << 21, device=DEV)
-        L.call("vqh_layernorm_bwd", dy, H, x, H, w, mean, rstd, dx, H, 1, dw, db, 0.0, rows, H, ws, ws.numel())
+        L.call("vqh_layernorm_bwd", dy, H, x, H, w, mean, rstd, dx, H, 1, dw, db, 0.0, rows, H, None, None, 0, 0.0, ws, ws.numel())
         assert rel(dx - 1.0, xr.grad) < 5e-6 and rel(dw, wr.grad) < 5e-6 and rel(db, br.grad) < 5e-6
+        # folded dropout backward: second output = dx * keep-mask(site), identical to the stand-alone pass
+        rng = torch.tensor([77, 3], device=DEV, dtype=torch.int64)
+        dx2, dxd = torch.zeros_like(x), torch.full_like(x, float("nan"))
+        L.call("vqh_layernorm_bwd", dy, H, x, H, w, mean, rstd, dx2, H, 0, dw, db, 0.0, rows, H, dxd, rng, 9, 0.2, ws, ws.numel())
+        want = torch.empty_like(x)
+        L.call("vqh_dropout_bwd", dx2, want, rows * H, rng, 9, 0.2)
+        assert rel(dx2, xr.grad) < 5e-6 and torch.equal(dxd, want)
+        assert 0.1 < float((dxd == 0).float().mean()) < 0.3
 
 
 @pytest.mark.parametrize("B,nh,T,S,dh,self_attn,ragged", [(3, 4, 24, 24, 16, True, True), (2, 8, 64, 64, 64, True, False),
@@ -411,6 +419,35 @@ def test_layer0_shared_projection_equals_per_sample_path():
         res.append((float(ld["loss"]), eng.flat_g.clone()))
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
     assert rel(res[0][1], res[1][1]) < 1e-4
+
+
+@pytest.mark.parametrize("width", ["small_rvq", "c2"])
+def test_folded_dropout_backward_equals_standalone_pass(width):
+    """With dropout ON, the LayerNorm backward of each block also writes dres * mask(next block's dropout site); the
+    gradients must be bit-identical to the path that runs the stand-alone dropout-backward kernel per site (a wrong
+    site pairing would silently train on wrong gradients; the golden vectors run with dropout off)."""
+    if width == "small_rvq":
+        name, cfg_kw, _r = MODEL_CASES[2]        # residual VQ, ragged
+        g = load_golden(name)
+        batches, sd0, weights = model_inputs(g, cfg_kw)
+        x, mask = batches[0]
+    else:                                        # true width (H=512, 4+2+4 layers), B=3, L=64
+        cfg_kw, weights = dict(G.C2_MODEL), dict(G.BASE_LOSS_WEIGHTS)
+        sd0 = G.model_state(cfg_kw, 77)
+        x, mask = G.curve_batch(3, 64, 78, ragged=True)
+    res = []
+    for fold in (True, False):
+        m, eng = _model(cfg_kw, sd0)
+        eng.drop_scale = 1.0                  # real dropout (p = 0.1 / tokenizer_dropout)
+        eng.fold_dropout_bwd = fold
+        eng.rng[0] = 4242
+        m.train()
+        ld = m.loss_function(*m(x.to(DEV), mask.to(DEV)), **weights)
+        m.backward()
+        torch.cuda.synchronize()
+        res.append((float(ld["loss"]), eng.flat_g.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]), float((res[0][1] - res[1][1]).abs().max())
 
 
 @pytest.mark.parametrize("name,cfg_kw,_r", MODEL_CASES)
