@@ -87,7 +87,7 @@ class StepEngine:
         # first decoder / tokenizer layer: project the batch-invariant queries once instead of per sample
         self.share_layer0 = os.environ.get("VQH_SHARE_LAYER0", "1") != "0"
         # dropout backward of a residual branch written by the LayerNorm backward that produces its input (ln_bwd emit)
-        self.fold_dropout_bwd = True
+        self.fold_dropout_bwd = os.environ.get("VQH_FOLD_DROPOUT_BWD", "1") != "0"
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
