@@ -257,12 +257,20 @@ class OracleVQVAE:
         o = (a @ v).transpose(1, 2).reshape(B, T, E)
         return linear(o, self._p(name + ".out_proj.weight"), self._p(name + ".out_proj.bias"))
 
+    def _relu(self, x, tag):
+        """ReLU; when self.taps is a dict the pre-activation is recorded under `tag` (tests use it to tell a genuine
+        difference from a unit whose pre-activation is within round-off of 0 and sits on the other side elsewhere)."""
+        taps = getattr(self, "taps", None)
+        if taps is not None:
+            taps[tag] = x.detach().clone()
+        return torch.relu(x)
+
     def _enc_layer(self, x, p, key_pad, nheads):
         # pre-LN encoder block (torch TransformerEncoderLayer, norm_first=True, relu)
         h = self._ln(x, p + ".norm1")
         x = x + self._drop(self._mha(h, h, p + ".self_attn", nheads, key_pad, 0.1), 0.1)
         h = self._ln(x, p + ".norm2")
-        h = self._drop(torch.relu(self._lin(h, p + ".linear1")), 0.1)
+        h = self._drop(self._relu(self._lin(h, p + ".linear1"), p + ".linear1"), 0.1)
         return x + self._drop(self._lin(h, p + ".linear2"), 0.1)
 
     def _dec_layer(self, x, mem, p, tgt_pad, nheads):
@@ -271,7 +279,7 @@ class OracleVQVAE:
         h = self._ln(x, p + ".norm2")
         x = x + self._drop(self._mha(h, mem, p + ".multihead_attn", nheads, None, 0.1), 0.1)
         h = self._ln(x, p + ".norm3")
-        h = self._drop(torch.relu(self._lin(h, p + ".linear1")), 0.1)
+        h = self._drop(self._relu(self._lin(h, p + ".linear1"), p + ".linear1"), 0.1)
         return x + self._drop(self._lin(h, p + ".linear2"), 0.1)
 
     # ---- model (models/vq_vae.py:639-765) ----------------------------------------------
@@ -328,8 +336,8 @@ class OracleVQVAE:
         if rows.numel() == 0 or idx.numel() == 0:
             return
         K, D = self.K, rows.shape[1]
-        cnt = torch.zeros(K).index_add_(0, idx, torch.ones(idx.shape[0]))
-        ssum = torch.zeros(K, D).index_add_(0, idx, rows)
+        cnt = torch.zeros(K, dtype=rows.dtype).index_add_(0, idx, torch.ones(idx.shape[0], dtype=rows.dtype))
+        ssum = torch.zeros(K, D, dtype=rows.dtype).index_add_(0, idx, rows)
         ecs, eemb, emb = (self.sd["quantizer.ema_cluster_size"], self.sd["quantizer.ema_embedding"],
                           self.sd["quantizer.embedding"])
         ecs.mul_(self.decay).add_(cnt * (1 - self.decay))
@@ -344,11 +352,11 @@ class OracleVQVAE:
 
     @torch.no_grad()
     def _usage_stats(self, idx_flat):
-        use = torch.bincount(idx_flat, minlength=self.K).float()
+        use = torch.bincount(idx_flat, minlength=self.K).to(self.sd["quantizer.embedding"].dtype)
         p = use / use.sum().clamp_min(1.0)
         nz = p > 0
         ppl = torch.exp(-(p[nz] * p[nz].log()).sum()) if bool(nz.any()) else torch.tensor(0.0)
-        dead = (use == 0).float().mean()
+        dead = (use == 0).to(use.dtype).mean()
         return use, ppl, dead
 
     def quantize(self, z_e, do_ema_update=True, mask=None):
@@ -450,7 +458,7 @@ class OracleVQVAE:
         d2 = (a - b).pow(2).sum(-1)
         if mask is None:
             return d2.mean(1)
-        m = mask.float()
+        m = mask.to(d2.dtype)
         return (d2 * m).sum(1) / m.sum(1).clamp_min(1.0)
 
     @staticmethod
@@ -458,7 +466,7 @@ class OracleVQVAE:
         """masked mean over everything; m None -> plain mean."""
         if m is None:
             return v.mean()
-        m = m.float()
+        m = m.to(v.dtype)
         return (v * m).sum() / m.sum().clamp_min(1.0)
 
     @staticmethod
@@ -470,14 +478,14 @@ class OracleVQVAE:
                 a_c, b_c = a - a_mu, b - b_mu
                 Hm = torch.einsum("bli,blj->bij", a_c, b_c)
             else:
-                m = mask.float()[..., None]
+                m = mask.to(a.dtype)[..., None]
                 den = m.sum(1, keepdim=True).clamp_min(1.0)
                 a_mu, b_mu = (a * m).sum(1, keepdim=True) / den, (b * m).sum(1, keepdim=True) / den
                 a_c, b_c = a - a_mu, b - b_mu
                 Hm = torch.einsum("bli,blj->bij", a_c * m, b_c)
             U, _, Vh = torch.linalg.svd(Hm)
-            sgn = (torch.det(U @ Vh) >= 0).float() * 2.0 - 1.0
-            Dm = torch.eye(3).repeat(a.shape[0], 1, 1)
+            sgn = (torch.det(U @ Vh) >= 0).to(a.dtype) * 2.0 - 1.0
+            Dm = torch.eye(3, dtype=a.dtype).repeat(a.shape[0], 1, 1)
             Dm[:, 2, 2] = sgn
             R = U @ Dm @ Vh
             t = b_mu - a_mu @ R
@@ -532,7 +540,7 @@ class OracleVQVAE:
                 mse = ((al - bw) ** 2).mean(dim=(1, 2))
                 sel = ok
             else:
-                m = sm.float()[..., None]
+                m = sm.to(al.dtype)[..., None]
                 mse = ((al - bw) ** 2 * m).sum(dim=(1, 2)) / m.sum(dim=(1, 2)).clamp_min(1.0)
                 sel = enough & ok
             if bool(sel.any()):

@@ -167,6 +167,9 @@ __global__ void vq_combine_kernel(const float* __restrict__ pbest, const float* 
             fs = dup ? fminf(fs, sc) : fminf(fs, b);
         }
     }
+    // a row of NaN (or Inf - Inf) scores never satisfies d < best: torch.argmin returns index 0 for an all-NaN row
+    // (/root/reference/models/vq_vae.py:188), and so does this; the loss then goes NaN instead of the gather faulting
+    if (fi == 0x7fffffff) fi = 0;
     idx_out[row] = (long long)fi + idx_offset;
     const float scale = znorm[row] + fabsf(fb) + 1e-30f;
     ambiguous[row] = ((fs - fb) <= rel_tol * scale) ? 1 : 0;

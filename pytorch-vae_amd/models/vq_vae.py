@@ -173,6 +173,7 @@ class VectorQuantizerEMA(nn.Module):
         eng = self._owner()._engine()
         eng.train = self.training
         eng.defer_ema = False
+        eng.use_arena(("vq", int(B), int(M)))
         with torch.no_grad():
             valid = None if mask is None else mask.to(device=z_e.device, dtype=torch.bool).reshape(B * M)
             z_st, z_q, idx, stats = eng.quantize(z_e.reshape(B * M, D).contiguous(), B, do_ema_update, row_valid=valid)
@@ -331,8 +332,17 @@ class VQVAE(nn.Module):
         dev = self.head_xyz.weight.device
         if dev.type != "cuda":
             raise _L.VqhError("VQVAE runs only on an MI355X: call .to('cuda') first (there is no CPU fallback)")
-        if self._eng is None or self._eng.dev != dev or not self._eng.params_in_sync():
+        old = self._eng
+        if old is None or old.dev != dev or not old.params_in_sync():
+            # parameters were re-homed (.to(), .float(), load into fresh tensors): rebuild the flat buffers, but keep the
+            # optimizer state and the dropout counter -- silently restarting AdamW would change the training run
             self._eng = StepEngine(self)
+            if old is not None and old.n_flat == self._eng.n_flat and old.offsets == self._eng.offsets:
+                self._eng.flat_m.copy_(old.flat_m)
+                self._eng.flat_v.copy_(old.flat_v)
+                self._eng.opt_step = old.opt_step
+                self._eng.rng.copy_(old.rng)
+                self._eng.drop_scale = old.drop_scale
         return self._eng
 
     @staticmethod
@@ -351,6 +361,7 @@ class VQVAE(nn.Module):
         x, mask = self._prep(x, mask)
         eng.train, eng.ctx = self.training, {}
         B, Lq, _ = x.shape
+        eng.use_arena((int(B), int(Lq)))
         hf, hg, hs = eng.encode(x, mask)
         H = self.hidden_dim
         return hf.view(B, Lq, H).clone(), hg.view(B, Lq, H).clone(), hs.view(B, Lq, H).clone()
@@ -360,6 +371,7 @@ class VQVAE(nn.Module):
         eng = self._engine()
         B, Lq, H = h_tokens.shape
         eng.train = self.training
+        eng.use_arena((int(B), int(Lq)))
         if eng.ctx is None:
             eng.ctx = {}
         eng.ctx.update({"B": B, "L": Lq, "mask": mask})
@@ -374,6 +386,7 @@ class VQVAE(nn.Module):
         B = z_for_decode.shape[0]
         Lq = mask.shape[1] if mask is not None else self.max_seq_len
         eng.train = self.training
+        eng.use_arena((int(B), int(Lq)))
         if eng.ctx is None:
             eng.ctx = {}
         z = z_for_decode.reshape(-1, self.code_dim).contiguous().float()
@@ -393,7 +406,9 @@ class VQVAE(nn.Module):
             idx_out = torch.zeros(B, N, dtype=torch.long, device=x.device)
             ppl = dead = torch.zeros((), device=x.device)
         vq_pack = (z_q.view(B, N, D), z_e.view(B, N, D), idx_out, ppl, dead)
-        return [rec.view(B, Lq, 6), x, vq_pack, mask]
+        rec_out = rec.view(B, Lq, 6)
+        rec_out._vqh_fwd_id = eng.fwd_id           # lets loss_function / backward check they belong to THIS forward
+        return [rec_out, x, vq_pack, mask]
 
     def loss_function(self, *args, **kwargs) -> dict:
         """Metric dict of the reference (:1357-1388).  `loss` carries a backward hook: calling
@@ -401,11 +416,21 @@ class VQVAE(nn.Module):
         recons, target, vq_pack = args[0], args[1], args[2]
         mask = args[3] if len(args) > 3 else None
         eng = self._engine()
-        z_q, z_e, _idx, _ppl, _dead = vq_pack
+        z_q, z_e, _idx, ppl, dead = vq_pack
         B, Lq = target.shape[0], target.shape[1]
-        rec2 = recons.reshape(B * Lq, 6)
-        metrics = eng.loss(rec2, target.contiguous(), mask, z_e.reshape(-1, self.code_dim),
-                           z_q.reshape(-1, self.code_dim), eng.vq_stats if self.use_vq else None, kwargs)
+        fid = getattr(recons, "_vqh_fwd_id", None)
+        if fid is not None and fid != eng.fwd_id:
+            raise _L.VqhError("loss_function: `recons` comes from an earlier forward; the engine keeps the activations of "
+                              "the LAST forward only (call loss_function right after its forward)")
+        rec2 = recons.reshape(B * Lq, 6).contiguous()
+        stats = None
+        if self.use_vq:                             # the perplexity / dead ratio the caller hands in (:1097, :1366-1367)
+            stats = eng.T("loss.stats_in", 2)
+            stats[0].copy_(torch.as_tensor(ppl, dtype=torch.float32))
+            stats[1].copy_(torch.as_tensor(dead, dtype=torch.float32))
+        metrics = eng.loss(rec2, target.contiguous(), mask, z_e.reshape(-1, self.code_dim).contiguous(),
+                           z_q.reshape(-1, self.code_dim).contiguous(), stats, kwargs)
+        eng.ctx["loss_fwd_id"] = fid               # None: tensors did not come from the engine -> no parameter gradients
         vals = metrics.clone()
         out = {}
         for i, k in enumerate(METRIC_KEYS):
@@ -413,8 +438,8 @@ class VQVAE(nn.Module):
             if wk is not None and not float(kwargs.get(wk, 0.0)) > 0:
                 continue
             out[k] = vals[i]
-        if torch.is_grad_enabled() and self.training:
-            out["loss"] = _LossBridge.apply(self._anchor(), vals[0], self)
+        if torch.is_grad_enabled() and self.training and fid is not None:
+            out["loss"] = _LossBridge.apply(self._anchor(), vals[0], self, fid)
         return out
 
     def _anchor(self):
@@ -461,6 +486,13 @@ class VQVAE(nn.Module):
                         "exp_avg_sq": eng.flat_v[o:o + k].view(eng.P[n].shape).clone()}
         return {"state": state, "param_groups": [{"params": list(range(len(names)))}]}
 
+    def engine_state(self):
+        """Engine state that is neither a weight nor an optimizer moment: the dropout counter [seed, step]."""
+        return {"rng": self._engine().rng.detach().cpu().clone()}
+
+    def load_engine_state(self, st):
+        self._engine().rng.copy_(torch.as_tensor(st["rng"], dtype=torch.int64))
+
     def load_optimizer_state(self, sd):
         eng = self._engine()
         names = [n for n, _ in self.named_parameters()]
@@ -473,10 +505,15 @@ class VQVAE(nn.Module):
             eng.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
             eng.opt_step = int(float(st["step"]))
 
-    def backward(self):
-        """Explicit HIP backward of the last forward + loss_function (fast path used by the trainer)."""
+    def backward(self, grad_scale: float = 1.0):
+        """Explicit HIP backward of the last forward + loss_function; fills param.grad (= grad_scale * d loss / d param)."""
         eng = self._engine()
+        if eng.ctx is None or eng.ctx.get("loss_fwd_id") != eng.fwd_id:
+            raise _L.VqhError("backward: no loss_function result for the engine's last forward (the loss was evaluated on "
+                              "other tensors, or another forward ran in between)")
         eng.backward()
+        if float(grad_scale) != 1.0:                # (loss / accum).backward(), loss scaling
+            eng.flat_g.mul_(float(grad_scale))
         eng.attach_grads()
         if getattr(self, "_grad_monitor_enabled", False):
             self._report_grads()
@@ -554,11 +591,15 @@ class _LossBridge(torch.autograd.Function):
     """Lets `loss_dict['loss'].backward()` (the Lightning-style call) trigger the HIP backward pass."""
 
     @staticmethod
-    def forward(ctx, anchor, loss_value, model):
-        ctx.model = model
+    def forward(ctx, anchor, loss_value, model, fwd_id):
+        ctx.model, ctx.fwd_id = model, fwd_id
         return loss_value.detach().clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.model.backward()          # gradients are for d(loss)/d(params) with upstream grad 1
-        return None, None, None
+        eng = ctx.model._engine()
+        if eng.fwd_id != ctx.fwd_id:
+            raise _L.VqhError("loss.backward(): another forward ran since this loss was computed; the engine holds the "
+                              "activations of the last forward only")
+        ctx.model.backward(grad_scale=float(grad_out))     # upstream gradient: (loss / accum).backward(), loss scaling
+        return None, None, None, None

@@ -112,6 +112,8 @@ class Trainer:
                 "pytorch-lightning_version": "1.9.0", "state_dict": sd, "hyper_parameters": dict(exp.hparams),
                 "optimizer_states": [exp.model.optimizer_state()] if hasattr(exp.model, "optimizer_state") else [],
                 "lr_schedulers": [exp.lr_policy.state_dict()] if exp.lr_policy is not None else []}
+        if hasattr(exp.model, "engine_state"):
+            ckpt["vqh_engine"] = exp.model.engine_state()      # dropout counter [seed, step]: masks continue after a resume
         tmp = path + ".tmp"
         torch.save(ckpt, tmp)
         os.replace(tmp, path)
@@ -125,5 +127,7 @@ class Trainer:
             exp.model.load_optimizer_state(ckpt["optimizer_states"][0])
         if ckpt.get("lr_schedulers") and exp.lr_policy is not None:
             exp.lr_policy.load_state_dict(ckpt["lr_schedulers"][0])
+        if ckpt.get("vqh_engine") is not None and hasattr(exp.model, "load_engine_state"):
+            exp.model.load_engine_state(ckpt["vqh_engine"])
         self.global_step = exp.global_step = int(ckpt.get("global_step", 0))
         return int(ckpt.get("epoch", -1))

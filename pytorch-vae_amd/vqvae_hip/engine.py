@@ -18,6 +18,7 @@ Memory layout in HBM (all fp32, row-major):
     attention reads heads in place from the packed QKV projection (no head transposes)
   * residual-stream gradient: one [rows, H] buffer per stack, updated in place layer by layer
 """
+import collections
 import os
 
 import torch
@@ -53,8 +54,33 @@ OPTIONAL_METRICS = {"Geom_LocalPDM": "pdm_weight", "Geom_WinKabsch": "win_kabsch
                     "Frenet_Tau": "tau_weight", "Geom_LongRangePDM": "lr_pdm_weight"}
 
 
+class _Arena:
+    """Every device buffer the step needs at ONE batch shape, plus the hipGraphs captured over them.  A captured graph
+    addresses its buffers by raw pointer, so buffers and graphs share one lifetime: an arena is only ever dropped whole
+    (LRU, StepEngine.use_arena).  Inside an arena a buffer is keyed by (name, shape, dtype) and never re-allocated."""
+    __slots__ = ("key", "pool", "buf", "graphs", "seen", "nbytes")
+
+    def __init__(self, key):
+        self.key = key
+        self.pool = {}                              # (name, shape, dtype) -> tensor, alive as long as the arena
+        self.buf = {}                               # name -> the tensor most recently handed out under that name
+        self.graphs = collections.OrderedDict()     # step key -> tuple of captured graphs (LRU, MAX_GRAPHS_PER_ARENA)
+        self.seen = {}
+        self.nbytes = 0
+
+    def release(self):
+        self.graphs.clear()                         # graphs first: they reference the buffers below
+        self.seen.clear()
+        self.buf.clear()
+        self.pool.clear()
+        self.nbytes = 0
+
+
+MAX_GRAPHS_PER_ARENA = 4
+
+
 class StepEngine:
-    def __init__(self, model, seed=0):
+    def __init__(self, model, seed=None):
         L.require_gpu()
         self.m = model
         self.dev = next(model.parameters()).device
@@ -65,17 +91,28 @@ class StepEngine:
         self.nh = model.num_heads
         self.tnh = model.tokenizer_heads
         self.N = model.latent_n_tokens
-        self.buf = {}
+        # batch-shape arenas (see _Arena): real data has a different L_max per batch (dataset.py:30-49) and a validation
+        # pass between train epochs (experiment.py:478-479); each shape keeps its own buffers + graphs, LRU-bounded
+        self.arenas = collections.OrderedDict()
+        self.max_arenas = int(os.environ.get("VQH_MAX_ARENAS", "8"))
+        self.max_arena_bytes = int(float(os.environ.get("VQH_ARENA_GIB", "0")) * (1 << 30)) or \
+            int(0.6 * torch.cuda.get_device_properties(self.dev).total_memory)
+        self.arena = None
+        self.buf = None
+        self.use_arena(("init",))
         self.ws = torch.empty(WS_FLOATS, device=self.dev, dtype=torch.float32)
+        # dropout counter-hash state [seed, step]; the seed follows torch.manual_seed (exp_params.manual_seed, run.py:119-121)
+        if seed is None:
+            seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         self.rng = torch.tensor([int(seed), 0], device=self.dev, dtype=torch.int64)
         self.drop_scale = 1.0                      # 0.0 disables every dropout site (parity runs)
         self._sites = {}
         self._flatten()
         self.hyper = torch.zeros(9, device=self.dev, dtype=torch.float32)
         self.metrics_acc = torch.zeros(len(METRIC_KEYS), device=self.dev, dtype=torch.float32)
-        self.graphs = {}
-        self._seen = {}
         self._pending_ema = None
+        self.fwd_id = 0                            # incremented by every forward: ties loss_function/backward to it
+        self.last_step_mode = None                 # "eager" | "capture" | "graph": how the last train_step ran
         self.norm = torch.zeros(2, device=self.dev, dtype=torch.float32)
         self.norm_ws = torch.empty(1024, device=self.dev, dtype=torch.float64)
         self.metrics = torch.zeros(len(METRIC_KEYS), device=self.dev, dtype=torch.float32)
@@ -137,11 +174,34 @@ class StepEngine:
             p.grad = self.G[n]
 
     # ------------------------------------------------------------------ buffers / helpers
+    def use_arena(self, key):
+        """Make the arena of batch-shape `key` current (creating it if needed) and evict least-recently-used arenas --
+        buffers AND the graphs that address them, together -- beyond max_arenas / max_arena_bytes."""
+        a = self.arenas.get(key)
+        if a is None:
+            a = self.arenas[key] = _Arena(key)
+        self.arenas.move_to_end(key)
+        self.arena, self.buf = a, a.buf
+        while len(self.arenas) > 1 and (len(self.arenas) > self.max_arenas or
+                                        sum(x.nbytes for x in self.arenas.values()) > self.max_arena_bytes):
+            old_key = next(iter(self.arenas))
+            if old_key == key:
+                break
+            torch.cuda.synchronize(self.dev)        # nothing in flight may still address the evicted buffers
+            self.arenas.pop(old_key).release()
+        return a
+
     def T(self, name, *shape, dtype=torch.float32):
-        t = self.buf.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(*shape, device=self.dev, dtype=dtype)
-            self.buf[name] = t
+        """Named device buffer of the current arena.  (name, shape, dtype) always maps to the same storage, so a graph
+        captured over it stays valid for the arena's lifetime; self.buf[name] is the latest tensor handed out as `name`."""
+        a = self.arena
+        k = (name, tuple(int(v) for v in shape), dtype)
+        t = a.pool.get(k)
+        if t is None:
+            t = torch.empty(*k[1], device=self.dev, dtype=dtype)
+            a.pool[k] = t
+            a.nbytes += t.numel() * t.element_size()
+        a.buf[name] = t
         return t
 
     def site(self, name):
@@ -721,6 +781,7 @@ class StepEngine:
         """VQVAE.forward (models/vq_vae.py:767-901) without aug/noise/soft-VQ (see DESIGN.md scope)."""
         self.train = bool(train)
         self.defer_ema = False
+        self.use_arena((int(x.shape[0]), int(x.shape[1])))
         x_in = self.augment_input(x)
         upd = self._host_prologue()
         out = self._forward_core(x_in, mask, upd)
@@ -772,6 +833,7 @@ class StepEngine:
     def _forward_core(self, x, mask, upd):
         m = self.m
         self.ctx = {}
+        self.fwd_id += 1
         B, Lq, _ = x.shape
         hf, _, _ = self.encode(x, mask)
         z_e = self.tokenize(hf, mask, B, Lq)
@@ -916,13 +978,38 @@ class StepEngine:
             self.maybe_reinit_dead_codes()
         return out
 
+    def _capturable(self, dp):
+        """Can this configuration's step live in hipGraphs?  A collective issued from INSIDE the forward cannot be
+        captured: with world_size > 1 that is residual VQ (per-level statistics reduce, models/vq_vae.py:251-258) and the
+        single-level usage-entropy regulariser (it reads the refreshed table, so the statistics are reduced in the forward).
+        Those run eager, phase by phase; everything else is captured."""
+        m = self.m
+        return not (dp and m.use_vq and (m.num_quantizers > 1 or not self.defer_ema))
+
+    def _replay(self, g, dp, upd, decay):
+        if not dp:
+            g[0].replay()
+            return
+        # graph segments = forward+loss+phase 0, phases 1..3, optimizer; one async all-reduce after each phase
+        self._pending_ema = decay if (upd and self.m.num_quantizers == 1) else None
+        works = []
+        for ph in range(len(BWD_PHASES)):
+            g[ph].replay()
+            self.allreduce_bucket(ph, works)
+        for w in works:
+            w.wait()
+        self._pending_ema = None
+        g[-1].replay()
+
     def _train_step(self, x, mask, weights, lr, weight_decay, clip, use_graph=True):
         """One whole training step (experiment.py:453 training_step + Lightning backward/clip/AdamW) on the GPU.
         Steady state = hipGraph replays; results land in self.metrics (device).  The captured graph holds every
-        kernel of the step; for world_size > 1 it is split around the single RCCL all-reduce."""
+        kernel of the step; for world_size > 1 it is split around the RCCL all-reduces.  Buffers and graphs belong to the
+        arena of this batch shape, so alternating shapes (ragged real data, validation passes) replay safely."""
         m = self.m
         self.train = True
         self.defer_ema = not (m.use_vq and float(m.usage_entropy_lambda) > 0.0)   # the regulariser reads the refreshed table
+        a = self.use_arena((int(x.shape[0]), int(x.shape[1])))
         xt = self.T("in.x", *x.shape)
         xt.copy_(x, non_blocking=True)
         x_in = self.augment_input(xt)             # eager, outside the graph (fresh torch random draws every step)
@@ -932,40 +1019,37 @@ class StepEngine:
         dp = dp_active()                          # data-parallel form of the step (world > 1)
         self.set_hyper(lr, weight_decay, clip, betas=getattr(self, "betas", (0.9, 0.999)), grad_scale=1.0 / world)
         decay = float(m.quantizer.decay) if m.use_vq else 0.0
-        key = (tuple(x.shape), mask is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
+        # everything a captured graph bakes in as a kernel argument (the batch shape is the arena)
+        key = (mask is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
                world, dp, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0),
-               x_in is xt, float(m.usage_entropy_lambda), self._soft_vq_key())
+               x_in is xt, float(m.usage_entropy_lambda), self._soft_vq_key(), self.share_layer0, self.fold_dropout_bwd,
+               float(m.xyz_align_alpha), float(m.ss_tv_lambda), m._data_std is not None)
         xs = x_in
         ms = None
         if mask is not None:
             ms = self.T("in.mask", *mask.shape, dtype=torch.bool)
             ms.copy_(mask, non_blocking=True)
-        g = self.graphs.get(key) if use_graph else None
+        use_graph = bool(use_graph) and os.environ.get("VQH_GRAPH", "1") != "0"
+        g = a.graphs.get(key) if use_graph else None
         if g is not None:
-            if not dp:
-                g[0].replay()
-                return self.metrics
-            # graph segments = forward+loss+phase 0, phases 1..3, optimizer; one async all-reduce after each phase
-            self._pending_ema = decay if (upd and m.num_quantizers == 1) else None
-            works = []
-            for ph in range(len(BWD_PHASES)):
-                g[ph].replay()
-                self.allreduce_bucket(ph, works)
-            for w in works:
-                w.wait()
-            self._pending_ema = None
-            g[-1].replay()
+            a.graphs.move_to_end(key)
+            self.last_step_mode = "graph"
+            self._replay(g, dp, upd, decay)
             return self.metrics
-        seen = self._seen.get(key, 0)
-        self._seen[key] = seen + 1
-        can_capture = use_graph and seen >= 1 and not (dp and m.use_vq and m.num_quantizers > 1)
-        if not can_capture:
+        if len(a.seen) > 64:                       # scheduled weights change every epoch: forget keys without a graph
+            a.seen = {k: v for k, v in a.seen.items() if k in a.graphs}
+        seen = a.seen.get(key, 0)
+        a.seen[key] = seen + 1
+        # the first step at a (shape, key) runs eager and allocates the arena; the second one captures
+        if not (use_graph and seen >= 1 and self._capturable(dp)):
+            self.last_step_mode = "eager"
             if dp:
                 self._step_eager_dp(xs, xt, ms, weights, upd)
             else:
                 self._step_part_a(xs, xt, ms, weights, upd)
                 self._step_part_b()
             return self.metrics
+        self.last_step_mode = "capture"
         torch.cuda.synchronize()
         graphs = []
         try:
@@ -984,40 +1068,27 @@ class StepEngine:
                             self._step_forward(xs, xt, ms, weights, upd)
                         self.backward_phase(ph)
                     graphs.append(gp)
-                pend = self._pending_ema
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     self._step_part_b()
                 graphs.append(gb)
-                self._pending_ema = pend
-        except Exception as e:          # capture refused (driver / collective state): stay on eager launches
-            print(f"[vqvae_hip] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
-            self._seen[key] = -(1 << 30)
+        except BaseException:
+            # No silent eager fallback: a failure inside capture is a bug in the step (or a configuration _capturable()
+            # should have excluded) and would otherwise hide behind slower launches.  VQH_GRAPH=0 runs without graphs.
             self._pending_ema = None
-            torch.cuda.synchronize()
-            if dp:
-                self._step_eager_dp(xs, xt, ms, weights, upd)
-            else:
-                self._step_part_a(xs, xt, ms, weights, upd)
-                self._step_part_b()
-            return self.metrics
-        self.graphs[key] = tuple(graphs)
-        if not dp:
-            graphs[0].replay()
-            return self.metrics
-        works = []
-        for ph in range(len(BWD_PHASES)):
-            graphs[ph].replay()
-            self.allreduce_bucket(ph, works)
-        for w in works:
-            w.wait()
+            a.seen.pop(key, None)
+            raise
         self._pending_ema = None
-        graphs[-1].replay()
+        a.graphs[key] = tuple(graphs)
+        while len(a.graphs) > MAX_GRAPHS_PER_ARENA:
+            a.graphs.popitem(last=False)
+        self._replay(a.graphs[key], dp, upd, decay)
         return self.metrics
 
     def eval_step(self, x, mask, weights):
         self.train = False
         self.defer_ema = False
+        self.use_arena((int(x.shape[0]), int(x.shape[1])))
         upd = self._host_prologue()
         rec, z_e, z_q, idx, stats = self._forward_core(x, mask, upd)
         self.loss(rec, x, mask, z_e, z_q, stats, weights)

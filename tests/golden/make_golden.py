@@ -55,6 +55,27 @@ def close(a, b, tol, what):
     return err
 
 
+def oracle64_step(cfg_kw, state32, x, mask, weights, clip, start_steps, train=True):
+    """fp64 re-evaluation of ONE step from the reference's fp32 pre-step state (the arbiter of how much of
+    a difference is fp32 round-off).  The reference itself is not dtype-generic (one-hot / eye / zeros are built as
+    float32: models/vq_vae.py:81-83, :959), so the re-evaluation runs the oracle -- asserted equal to the reference in
+    fp32 on this very step -- on .double() copies of the reference's weights and buffers."""
+    cfg = O.make_cfg(**cfg_kw)
+    sd = {k: (v.detach().clone().double() if v.is_floating_point() else v.detach().clone()) for k, v in state32.items()}
+    sd = O.attach_grads(sd, cfg)
+    orc = O.OracleVQVAE(sd, drop_scale=0.0, **cfg_kw)
+    orc.training = train
+    orc.training_steps = start_steps
+    out = orc.forward(x.double(), mask)
+    ld = orc.loss_function(*out, **weights)
+    grads, gn = {}, None
+    if train:
+        ld["loss"].backward()
+        gn = torch.nn.utils.clip_grad_norm_(orc.params(), clip) if clip and clip > 0 else None
+        grads = {k: sd[k].grad.detach().clone() for k in O.param_shapes(cfg)}
+    return out, ld, grads, gn
+
+
 def close_step(a, b, lr, what, nsteps=1):
     """Post-AdamW weights: the first Adam update is ~lr*sign(g), so an element whose gradient is
     at round-off level (e.g. the key bias of an attention in_proj, whose true gradient is zero)
@@ -165,6 +186,7 @@ def model_case(name, cfg_kw, B, L, seed, ragged, weights, lr=1e-3, wd=0.01, clip
     for s in range(steps):
         x, mask = batches[s]
         out[f"x_sum_{s}"] = G.checksum(x)
+        o64, ld64, g64, gn64 = oracle64_step(cfg_kw, ref.state_dict(), x, mask, weights, clip, ref.training_steps)
         opt_r.zero_grad(set_to_none=True)
         r = ref(x, mask)
         ld = ref.loss_function(*r, **weights)
@@ -196,6 +218,16 @@ def model_case(name, cfg_kw, B, L, seed, ragged, weights, lr=1e-3, wd=0.01, clip
         out[f"grad_norm_{s}"] = float(gn)
         out[f"gradnorm_each_{s}"] = np.array([float(grads_r[k].norm()) for k in pnames])
         out[f"post_sum_each_{s}"] = np.array([G.checksum(ref.state_dict()[k]) for k in pnames])
+        # fp64 re-evaluation of the same step (arbiter): its distance to the fp32 reference bounds the fp32 round-off
+        if cfg["use_vq"]:
+            assert torch.equal(o64[2][2].reshape(-1), r[2][2].reshape(-1)), f"{name}: fp64 argmin differs from fp32"
+        out[f"loss_vals64_{s}"] = np.array([float(ld64[k]) for k in ld], dtype=np.float64)
+        out[f"recons_err64_{s}"] = float((o64[0].detach() - r[0].detach().double()).abs().max())
+        out[f"z_e_err64_{s}"] = float((o64[2][1].detach() - r[2][1].detach().double()).abs().max())
+        out[f"grad_norm64_{s}"] = float(gn64)
+        out[f"gradnorm_each64_{s}"] = np.array([float(g64[k].norm()) for k in pnames])
+        out[f"grad_maxerr64_each_{s}"] = np.array([float((g64[k] - grads_r[k].double()).abs().max()) for k in pnames])
+        out[f"grad_maxabs_each_{s}"] = np.array([float(grads_r[k].abs().max()) for k in pnames])
         if full_grads:
             for k in GRAD_KEYS_FULL:
                 if k in grads_r:
@@ -220,6 +252,9 @@ def model_case(name, cfg_kw, B, L, seed, ragged, weights, lr=1e-3, wd=0.01, clip
             ro = orc.forward(x, mask)
             ld = ref.loss_function(*r, **weights)
             ldo = orc.loss_function(*ro, **weights)
+            o64, ld64, _, _ = oracle64_step(cfg_kw, sd0, x, mask, weights, clip, 0, train=False)
+        out["eval_loss_vals64"] = np.array([float(ld64[k]) for k in ld], dtype=np.float64)
+        out["eval_recons_err64"] = float((o64[0] - r[0].double()).abs().max())
         close(ro[0], r[0], 2e-5, f"{name} eval recons")
         for k in ld:
             close(ldo[k], ld[k], 3e-5, f"{name} eval loss[{k}]")
@@ -268,6 +303,17 @@ def loss_case(name, B, L, seed, ragged, weights, cfg_kw, noise=0.7, data_stats=N
         pack2 = (zq, z2, pack[2], pack[3], pack[4])
         ldo = orc.loss_function(r2, x, pack2, m, **weights)
         ldo["loss"].backward()
+        # fp64 re-evaluation (arbiter of fp32 round-off), same oracle on .double() inputs
+        sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        orc64 = O.OracleVQVAE(sd64, drop_scale=0.0, **cfg_kw)
+        if data_stats is not None:
+            orc64.data_mean, orc64.data_std = mean.double().view(1, 1, 3), std.double().view(1, 1, 3)
+        r3, z3 = rec.double().requires_grad_(True), ze.double().requires_grad_(True)
+        ld64 = orc64.loss_function(r3, x.double(), (zq.double(), z3, pack[2], pack[3].double(), pack[4].double()), m, **weights)
+        ld64["loss"].backward()
+        out[f"{tag}_loss_vals64"] = np.array([float(ld64[k]) for k in ld], dtype=np.float64)
+        out[f"{tag}_d_recons_err64"] = float((r3.grad - r1.grad.double()).abs().max())
+        out[f"{tag}_d_ze_err64"] = float((z3.grad - z1.grad.double()).abs().max())
         for k in ld:
             close(ldo[k], ld[k], 2e-5, f"{name}/{tag} loss[{k}]")
         close(r2.grad, r1.grad, 1e-4, f"{name}/{tag} d_recons")
@@ -303,6 +349,83 @@ def init_case(name, cfg_kw, seed):
     print(f"[golden] {name}: {len(keys)} keys, {out['n_params']} params")
 
 
+# ------------------------------------------------------------------------------------------
+# 5. harness pieces that live behind `import pytorch_lightning` (not installed): the two PURE functions are taken out
+#    of the reference source with ast and executed on their own -- no Lightning import, no stub.
+# ------------------------------------------------------------------------------------------
+def _extract_function(path, fn_name, namespace):
+    import ast
+    src = open(path).read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fn_name)
+    mod = ast.Module(body=[node], type_ignores=[])
+    exec(compile(mod, f"<{os.path.basename(path)}:{fn_name}>", "exec"), namespace)
+    return namespace[fn_name]
+
+
+def harness_case(name="harness"):
+    import yaml
+    from typing import Dict, List, Tuple
+    from torch.nn.utils.rnn import pad_sequence
+    interp = _extract_function(os.path.join(REF, "experiment.py"), "interpolate_schedule", {"Dict": Dict, "List": List})
+    collate = _extract_function(os.path.join(REF, "dataset.py"), "pad_collate",
+                                {"List": List, "Tuple": Tuple, "torch": torch, "pad_sequence": pad_sequence})
+    out = {}
+    for stem in ("stage1_ae", "stage2_vq"):
+        with open(os.path.join(REF, "configs", stem + ".yaml")) as f:
+            cfg = yaml.safe_load(f)
+        sched = cfg["exp_params"].get("schedules", {}) or {}
+        keys = sorted(sched.keys())
+        vals = np.zeros((len(keys), 201), dtype=np.float64)
+        for e in range(201):
+            row = interp(sched, e)
+            assert sorted(row.keys()) == keys
+            vals[:, e] = [row[k] for k in keys]
+        out[f"{stem}_sched_keys"] = np.array(keys)
+        out[f"{stem}_sched_vals"] = vals
+        ep = cfg["exp_params"]
+        # torch's own schedulers with the YAML's parameters (experiment.py:176-197): lr and Adam beta1 per step / epoch
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=float(ep["LR"]))
+        epochs, spe = 6, 11
+        sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=float(ep["LR"]), epochs=epochs, steps_per_epoch=spe,
+                                                  pct_start=float(ep.get("onecycle_pct_start", 0.15)), anneal_strategy="cos",
+                                                  div_factor=float(ep.get("onecycle_div_factor", 25.0)),
+                                                  final_div_factor=float(ep.get("onecycle_final_div", 1500.0)))
+        lrs, b1 = [], []
+        for _ in range(epochs * spe):
+            lrs.append(opt.param_groups[0]["lr"])
+            b1.append(opt.param_groups[0]["betas"][0])
+            opt.step()
+            sch.step()
+        out[f"{stem}_onecycle"] = np.array([lrs, b1], dtype=np.float64)
+        out[f"{stem}_onecycle_cfg"] = np.array([float(ep["LR"]), epochs, spe, float(ep.get("onecycle_pct_start", 0.15)),
+                                                float(ep.get("onecycle_div_factor", 25.0)),
+                                                float(ep.get("onecycle_final_div", 1500.0))])
+        opt = torch.optim.AdamW([p], lr=float(ep["LR"]))
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=12, eta_min=float(ep["LR"]) * 1e-6)
+        lrs = []
+        for _ in range(12):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[f"{stem}_cosine"] = np.array(lrs, dtype=np.float64)
+    g = torch.Generator().manual_seed(4711)
+    lens = [5, 17, 1, 9, 17, 12]
+    items = [torch.randn(n, 6, generator=g) for n in lens]
+    xb, mb = collate([t.clone() for t in items])
+    out["collate_lens"] = np.array(lens)
+    out["collate_x"] = np_(xb)
+    out["collate_mask"] = np_(mb)
+    try:
+        collate([])
+        out["collate_empty_raises"] = 0
+    except RuntimeError:
+        out["collate_empty_raises"] = 1
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"[golden] {name}: schedules of both YAMLs (epochs 0-200), pad_collate, OneCycle / cosine traces")
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     want = lambda n: (not only) or (n in only)
@@ -320,7 +443,7 @@ if __name__ == "__main__":
     if want("model"):
         model_case("model_small_vq_full", G.SMALL_VQ, 6, 24, 21, False, G.BASE_LOSS_WEIGHTS, steps=2)
         model_case("model_small_vq_ragged", G.SMALL_VQ, 5, 37, 22, True, G.ALL_LOSS_WEIGHTS, smooth=True, steps=2)
-        model_case("model_small_rvq_ragged", G.SMALL_RVQ, 4, 32, 23, True, G.ALL_LOSS_WEIGHTS, smooth=True)
+        model_case("model_small_rvq_ragged", G.SMALL_RVQ, 4, 32, 23, True, G.ALL_LOSS_WEIGHTS, smooth=True, steps=3)
         model_case("model_small_ae", G.SMALL_AE, 8, 40, 24, True, dict(ss_weight=0.6, xyz_tv_lambda=0.006), clip=1.0)
     if want("extra"):
         model_case("model_small_softvq", dict(G.SMALL_VQ, soft_vq_use=True, soft_vq_tau_start=2.0, soft_vq_tau_end=0.5,
@@ -338,6 +461,8 @@ if __name__ == "__main__":
         loss_case("loss_all_ragged", 5, 48, 31, True, G.ALL_LOSS_WEIGHTS, dict(G.SMALL_VQ, usage_entropy_lambda=0.01))
         loss_case("loss_all_full", 4, 64, 32, False, G.ALL_LOSS_WEIGHTS, G.SMALL_VQ)
         loss_case("loss_short", 3, 9, 33, False, G.ALL_LOSS_WEIGHTS, G.SMALL_VQ)
+    if want("harness"):
+        harness_case()
     if want("init"):
         init_case("init_small_vq_seed1265", G.SMALL_VQ, 1265)
         init_case("init_c2_seed1265", G.C2_MODEL, 1265)

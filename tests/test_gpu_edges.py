@@ -8,21 +8,29 @@ import torch
 
 import gen_inputs as G
 from gen_inputs import O
+from parity_util import assert_scalar, assert_tensor
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _oracle(cfg_kw, sd0, x, mask, weights, dtype):
+    cfg = O.make_cfg(**cfg_kw)
+    sd = O.attach_grads({k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}, cfg)
+    orc = O.OracleVQVAE(sd, drop_scale=0.0, **cfg_kw)
+    orc.training_steps = 1
+    orc.taps = {}
+    out = orc.forward(x.to(dtype), mask)
+    ld = orc.loss_function(*out, **weights)
+    ld["loss"].backward()
+    return out, ld, sd, orc.taps
+
+
 def _both(cfg_kw, x, mask, weights, seed=5):
     from models import vae_models
     sd0 = G.model_state(cfg_kw, seed)
-    cfg = O.make_cfg(**cfg_kw)
-    sd = O.attach_grads({k: v.clone() for k, v in sd0.items()}, cfg)
-    orc = O.OracleVQVAE(sd, drop_scale=0.0, **cfg_kw)
-    orc.training_steps = 1
-    out_o = orc.forward(x, mask)
-    ld_o = orc.loss_function(*out_o, **weights)
-    ld_o["loss"].backward()
+    o32 = _oracle(cfg_kw, sd0, x, mask, weights, torch.float32)
+    o64 = _oracle(cfg_kw, sd0, x, mask, weights, torch.float64)        # arbiter of the fp32 round-off (parity_util.py)
     m = vae_models["VQVAE"](**cfg_kw)
     m.load_state_dict(sd0, strict=True)
     m = m.to(DEV).train()
@@ -30,29 +38,67 @@ def _both(cfg_kw, x, mask, weights, seed=5):
     eng = m._engine()
     eng.drop_scale = 0.0
     out = m(x.to(DEV), mask.to(DEV))
+    # post-ReLU activations of every FFN, before backward overwrites them with gradients (engine.ffn_block_bwd)
+    acts = {k[:-2]: v.clone() for k, v in eng.buf.items() if k.endswith(".linear1.y")}
     ld = m.loss_function(*out, **weights)
     m.backward()
     torch.cuda.synchronize()
-    return (out, ld, eng), (out_o, ld_o, sd)
+    return (out, ld, eng, acts), o32, o64
 
 
-def _check(hip, orc, cfg_kw, tol=1e-4, gtol=2e-3):
-    # tolerances: the dihedral / Frenet-tau terms divide by |b1 x b2| and are ill-conditioned in fp32 (3e-5 rel on the
-    # loss at L=5); ReLU pre-activations within round-off of 0 flip between implementations, which moves single
-    # FFN weight-gradient entries by ~1e-3 of the tensor's max (everything else agrees to ~1e-4).
-    (out, ld, eng), (out_o, ld_o, sd) = hip, orc
+def _relu_flips(acts, taps, mask):
+    """FFN units whose ReLU is open on one side and closed on the other.  A pre-activation within round-off of 0 lands on
+    either side depending on the summation order (the oracle's own fp64 run disagrees with its fp32 run equally often:
+    ~1e-6 of the units, i.e. about one per FFN at B*L*2048 = 1.4 M units); the gradient of that unit is then present
+    on one side only.  Returns {stack: count} over valid rows, with the largest |pre-activation| involved."""
+    flips, worst = {}, 0.0
+    valid = mask.reshape(-1)
+    for name, pre in taps.items():
+        a = acts[name].cpu().reshape(-1, pre.shape[-1])
+        p = pre.reshape(-1, pre.shape[-1])
+        diff = ((a > 0) != (p > 0)) & valid[:, None]
+        n = int(diff.sum())
+        if n:
+            flips[name.split(".")[0]] = flips.get(name.split(".")[0], 0) + n
+            worst = max(worst, float(p[diff].abs().max() / p.abs().max()))
+    return flips, worst
+
+
+# backward order: a flip in a stack perturbs the gradients of that stack and of everything backward reaches after it
+_UPSTREAM = {"decoder": None,                                             # everything
+             "ss_encoder": ("ss_encoder.", "ss_input_proj."),
+             "encoder": ("encoder.", "input_proj.")}
+
+
+def _check(hip, o32, o64, cfg_kw):
+    """Forward quantities and losses: 1e-5 relative, fp64-arbitrated (parity_util.py; the dihedral / Frenet-tau terms
+    divide by |b1 x b2| and are ill-conditioned in fp32 at L=5: there the reference's own fp32 error is the looser
+    bound).  Gradients: the same rule for every tensor, except those reached by a DETECTED ReLU flip (see _relu_flips),
+    which are bounded at 2e-3 of the tensor's max instead; the flipped pre-activations must be at round-off level."""
+    (out, ld, eng, acts), (out_o, ld_o, sd, taps), (out_64, ld_64, sd64, _) = hip, o32, o64
     m = out[3].cpu()
-    rec, rec_o = out[0].cpu() * m[..., None], out_o[0].detach() * m[..., None]       # padded rows are don't-care
-    assert float((rec - rec_o).abs().max()) <= tol * max(1.0, float(rec_o.abs().max()))
+    rec, rec_o, rec_64 = out[0].cpu() * m[..., None], out_o[0].detach() * m[..., None], out_64[0].detach() * m[..., None]
+    assert_tensor(rec, rec_o, float((rec_o.double() - rec_64).abs().max()), "recons")   # padded rows are don't-care
     if cfg_kw.get("use_vq", True):
         assert torch.equal(out[2][2].cpu().reshape(-1), out_o[2][2].reshape(-1))
     for k, v in ld_o.items():
-        v = float(v)
-        assert abs(float(ld[k]) - v) <= tol * max(1.0, abs(v)), (k, float(ld[k]), v)
-    gmax = max(float(sd[k].grad.abs().max()) for k in O.param_shapes(O.make_cfg(**cfg_kw)))
-    for k in O.param_shapes(O.make_cfg(**cfg_kw)):
-        d = float((eng.G[k].cpu() - sd[k].grad).abs().max())
-        assert d <= gtol * max(float(sd[k].grad.abs().max()), 1e-3 * gmax), (k, d)
+        assert_scalar(ld[k], float(v), float(ld_64[k]), f"loss[{k}]")
+    flips, worst = _relu_flips(acts, taps, m)
+    assert worst <= 1e-5, f"ReLU masks differ at pre-activations that are NOT round-off ({worst:.2e} of the max): {flips}"
+    loose = ()
+    for stack in flips:
+        loose = None if (loose is None or _UPSTREAM[stack] is None) else loose + _UPSTREAM[stack]
+    names = list(O.param_shapes(O.make_cfg(**cfg_kw)))
+    gmax = max(float(sd[k].grad.abs().max()) for k in names)
+    for k in names:
+        g32, g64 = sd[k].grad.double(), sd64[k].grad
+        d = float((eng.G[k].cpu().double() - g32).abs().max())
+        scale = max(float(g32.abs().max()), 1e-3 * gmax)
+        if loose is None or k.startswith(loose):
+            assert d <= 2e-3 * scale, (k, d, scale, flips)
+        else:
+            tol = max(1e-5 * scale, 4.0 * float((g32 - g64).abs().max())) + 1e-12
+            assert d <= tol, (k, d, tol, flips)
 
 
 @pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 9])

@@ -2,8 +2,9 @@
 """GPU parity suite (-m gpu): the HIP path, called through the C ABI, against
   * the committed golden vectors recorded from the real reference (tests/golden/*.npz), and
   * the CPU oracle (oracle/vqvae_oracle.py) on the same seeded inputs.
-Tolerances (north_star): code indices bit-exact; losses / reconstructions / gradients within 1e-5
-relative in fp32 up to the fp32 summation-order noise of a different GEMM (documented per test)."""
+Tolerances (north_star): code indices bit-exact; losses / reconstructions / gradients within 1e-5 relative in fp32,
+with the reference's own fp32 round-off arbitrated by an fp64 re-evaluation recorded in the fixtures
+(tests/parity_util.py: |got - ref32| <= max(1e-5 |ref32|, 4 |ref32 - ref64|) + 1e-8)."""
 import math
 import os
 
@@ -14,6 +15,7 @@ import torch
 import gen_inputs as G
 from gen_inputs import O
 from conftest import load_golden
+from parity_util import assert_losses, assert_tensor, assert_scalar
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -324,8 +326,9 @@ def test_quantizer_bit_exact_vs_oracle_at_c2_shape():
 # ------------------------------------------------------------------------------------------------
 # loss function alone (all 19+5 terms, forward value and input gradients)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name,cfg_kw", [("loss_all_ragged", dict(G.SMALL_VQ)), ("loss_all_full", G.SMALL_VQ),
-                                         ("loss_short", G.SMALL_VQ), ("loss_datastats", G.SMALL_VQ)])
+@pytest.mark.parametrize("name,cfg_kw", [("loss_all_ragged", dict(G.SMALL_VQ, usage_entropy_lambda=0.01)),
+                                         ("loss_all_full", G.SMALL_VQ), ("loss_short", G.SMALL_VQ),
+                                         ("loss_datastats", G.SMALL_VQ)])
 def test_loss_function_matches_reference_golden(name, cfg_kw):
     g = load_golden(name)
     sd0 = G.model_state(cfg_kw, int(g["seed"]))
@@ -337,37 +340,21 @@ def test_loss_function_matches_reference_golden(name, cfg_kw):
     x, mask = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
     rec, ze, zq = (torch.from_numpy(g[k]).to(DEV) for k in ("recons", "ze", "zq"))
     B, Nt = ze.shape[:2]
-    orc = O.OracleVQVAE({k: v.clone() for k, v in sd0.items()}, drop_scale=0.0, **cfg_kw)
     for tag, mk in (("m", mask), ("nomask", None)):
+        # perplexity / dead ratio travel through vq_pack, like the reference's call (models/vq_vae.py:1097)
         pack = (zq, ze, torch.zeros(B, Nt, dtype=torch.long, device=DEV), torch.tensor(3.0, device=DEV), torch.tensor(0.5, device=DEV))
-        eng.vq_stats.copy_(torch.tensor([3.0, 0.5]))
         ld = m.loss_function(rec, x, pack, mk, **weights)
-        want = dict(zip([str(k) for k in g[f"{tag}_loss_keys"]], g[f"{tag}_loss_vals"]))
-        if name == "loss_all_ragged":      # that fixture was recorded with usage_entropy_lambda=0.01 (not on the HIP path)
-            r1, z1 = torch.from_numpy(g["recons"]).requires_grad_(True), torch.from_numpy(g["ze"]).requires_grad_(True)
-            lo = orc.loss_function(r1, torch.from_numpy(g["x"]), (torch.from_numpy(g["zq"]), z1, None, torch.tensor(3.0), torch.tensor(0.5)),
-                                   None if mk is None else torch.from_numpy(g["mask"]), **weights)
-            lo["loss"].backward()
-            want = {k: float(v) for k, v in lo.items()}
-            d_rec_want, d_ze_want = r1.grad, z1.grad
-        else:
-            d_rec_want, d_ze_want = g[f"{tag}_d_recons"], g[f"{tag}_d_ze"]
-        for k, v in want.items():
-            got = float(ld[k])
-            assert abs(got - v) <= 2e-5 * max(1.0, abs(v)), f"{tag} {k}: {got} vs {v}"
-        assert rel(eng.ctx["d_rec"].view(B, -1, 6), d_rec_want) < 2e-4
-        assert rel(eng.ctx["d_ze"].view(B, Nt, -1), d_ze_want) < 1e-5
+        assert_losses(ld, g[f"{tag}_loss_keys"], g[f"{tag}_loss_vals"], g[f"{tag}_loss_vals64"], f"{name}/{tag}")
+        assert_tensor(eng.ctx["d_rec"].view(B, -1, 6), g[f"{tag}_d_recons"], g[f"{tag}_d_recons_err64"], f"{name}/{tag} d_recons")
+        assert_tensor(eng.ctx["d_ze"].view(B, Nt, -1), g[f"{tag}_d_ze"], g[f"{tag}_d_ze_err64"], f"{name}/{tag} d_ze")
 
 
 # ------------------------------------------------------------------------------------------------
 # whole model: forward + loss + backward (+ AdamW) against the reference golden vectors
 # ------------------------------------------------------------------------------------------------
-def _grad_tol(name):
-    return 3e-4
-
-
 @pytest.mark.parametrize("name,cfg_kw,_r", MODEL_CASES + EXTRA_CASES)
 def test_train_step_matches_reference_golden(name, cfg_kw, _r):
+    """The decomposed drop-in surface: forward -> loss_function -> loss.backward() -> clip + AdamW."""
     g = load_golden(name)
     batches, sd0, weights = model_inputs(g, cfg_kw)
     m, eng = _model(cfg_kw, sd0)
@@ -376,29 +363,31 @@ def test_train_step_matches_reference_golden(name, cfg_kw, _r):
     x, mask = batches[0]
     out = m(x.to(DEV), mask.to(DEV))
     ld = m.loss_function(*out, **weights)
-    assert rel(out[0], g["recons_0"]) < 2e-5
-    assert rel(out[2][1], g["z_e_0"]) < 2e-5
+    assert_tensor(out[0], g["recons_0"], g["recons_err64_0"], "recons")
+    assert_tensor(out[2][1], g["z_e_0"], g["z_e_err64_0"], "z_e")
     if m.use_vq:
         assert np.array_equal(out[2][2].reshape(-1).cpu().numpy().astype(np.int32), g["idx_0"]), "code indices must be bit-exact"
-    for k, v in zip(g["loss_keys_0"], g["loss_vals_0"]):
-        assert abs(float(ld[str(k)]) - v) <= 3e-5 * max(1.0, abs(v)), f"{k}: {float(ld[str(k)])} vs {v}"
+    assert_losses(ld, g["loss_keys_0"], g["loss_vals_0"], g["loss_vals64_0"], name)
     m.backward()
     eng.set_hyper(float(g["lr"]), float(g["wd"]), float(g["clip"]))
     eng.optimizer_step()        # clips the flat gradient in place (like clip_grad_norm_) then AdamW
     torch.cuda.synchronize()
-    assert abs(float(eng.norm[0]) - float(g["grad_norm_0"])) <= 2e-4 * float(g["grad_norm_0"])
+    assert_scalar(eng.norm[0], g["grad_norm_0"], g["grad_norm64_0"], "total gradient norm")
     pnames = [str(k) for k in g["param_names"]]
-    gne = np.array([float(eng.G[k].norm()) for k in pnames])
-    want = g["gradnorm_each_0"]
-    assert np.allclose(gne, want, rtol=3e-3, atol=2e-6 * float(g["grad_norm_0"]) + 1e-9), \
-        [(k, a, b) for k, a, b in zip(pnames, gne, want) if abs(a - b) > 3e-3 * abs(b) + 2e-6 * float(g["grad_norm_0"])][:5]
+    # per-tensor gradient norms (post-clip, like the fixture): ||g_hip|| within the arbiter rule of ||g_ref||; the
+    # reference's own distance to fp64 is an upper bound of |  ||g32|| - ||g64||  | via the max-error * sqrt(n)
+    for i, k in enumerate(pnames):
+        n32, n64 = float(g["gradnorm_each_0"][i]), float(g["gradnorm_each64_0"][i])
+        got = float(eng.G[k].norm())
+        tol = max(1e-5 * n32, 4.0 * abs(n32 - n64)) + 1e-5 * float(g["grad_maxabs_each_0"].max()) * 1e-2 + 1e-12
+        assert abs(got - n32) <= tol, f"||grad {k}||: {got} vs {n32} (tol {tol:.3e})"
     for key in g:
         if key.startswith("grad_0::"):
             k = key.split("::")[1]
-            assert rel(eng.G[k], g[key]) < _grad_tol(k) or float(np.abs(g[key]).max()) < 1e-7, k
+            assert_tensor(eng.G[k], g[key], float(g["grad_maxerr64_each_0"][pnames.index(k)]), f"grad {k}")
     if m.use_vq:
-        assert rel(m.quantizer.embedding, g["q_emb_0"]) < 1e-5
-        assert rel(m.quantizer.ema_cluster_size, g["q_ecs_0"]) < 1e-6
+        assert_tensor(m.quantizer.embedding, g["q_emb_0"], None, "codebook")
+        assert_tensor(m.quantizer.ema_cluster_size, g["q_ecs_0"], None, "ema_cluster_size")
 
 
 def test_layer0_shared_projection_equals_per_sample_path():
@@ -460,12 +449,11 @@ def test_eval_forward_decode_match_reference_golden(name, cfg_kw, _r):
     with torch.no_grad():
         out = m(x.to(DEV), mask.to(DEV))
         ld = m.loss_function(*out, **weights)
-    assert rel(out[0], g["eval_recons"]) < 2e-5
+    assert_tensor(out[0], g["eval_recons"], g["eval_recons_err64"], "eval recons")
     if m.use_vq:
         assert np.array_equal(out[2][2].reshape(-1).cpu().numpy().astype(np.int32), g["eval_idx"])
-    for k, v in zip(g["eval_loss_keys"], g["eval_loss_vals"]):
-        assert abs(float(ld[str(k)]) - v) <= 3e-5 * max(1.0, abs(v)), k
-    assert rel(m.decode(out[2][0], mask.to(DEV)), g["eval_decode"]) < 2e-5
+    assert_losses(ld, g["eval_loss_keys"], g["eval_loss_vals"], g["eval_loss_vals64"], f"{name} eval")
+    assert_tensor(m.decode(out[2][0], mask.to(DEV)), g["eval_decode"], g["eval_recons_err64"], "decode")
     # encode / _tokenize_to_codes entry points used by the reference's scripts
     hf, hg, hs = m.encode(x.to(DEV), mask.to(DEV))
     z = m._tokenize_to_codes(hf, mask.to(DEV))
@@ -481,15 +469,20 @@ def test_true_width_c2_model_b2_matches_reference_golden():
     x, mask = batches[0]
     out = m(x.to(DEV), mask.to(DEV))
     ld = m.loss_function(*out, **weights)
-    assert rel(out[0], g["recons_0"]) < 2e-5 and rel(out[2][1], g["z_e_0"]) < 2e-5
+    assert_tensor(out[0], g["recons_0"], g["recons_err64_0"], "recons")
+    assert_tensor(out[2][1], g["z_e_0"], g["z_e_err64_0"], "z_e")
     assert np.array_equal(out[2][2].reshape(-1).cpu().numpy().astype(np.int32), g["idx_0"])
-    for k, v in zip(g["loss_keys_0"], g["loss_vals_0"]):
-        assert abs(float(ld[str(k)]) - v) <= 3e-5 * max(1.0, abs(v)), k
+    assert_losses(ld, g["loss_keys_0"], g["loss_vals_0"], g["loss_vals64_0"], "c2_b2")
     m.backward()
     torch.cuda.synchronize()
     pnames = [str(k) for k in g["param_names"]]
-    gne = np.array([float(eng.G[k].norm()) for k in pnames]) * min(1.0, float(g["clip"]) / (float(g["grad_norm_0"]) + 1e-6))
-    assert np.allclose(gne, g["gradnorm_each_0"], rtol=3e-3, atol=2e-6 * float(g["grad_norm_0"]))
+    cl = min(1.0, float(g["clip"]) / (float(g["grad_norm_0"]) + 1e-6))
+    for i, k in enumerate(pnames):
+        n32, n64 = float(g["gradnorm_each_0"][i]), float(g["gradnorm_each64_0"][i])
+        got = float(eng.G[k].norm()) * cl
+        # ||g32 - g64|| <= sqrt(n) * max-error: the fp32 reference's own distance to the exact gradient norm
+        noise = float(g["grad_maxerr64_each_0"][i]) * float(np.sqrt(eng.G[k].numel()))
+        assert abs(got - n32) <= max(1e-5 * n32, 4.0 * abs(n32 - n64), noise) + 1e-12, (k, got, n32, n64)
 
 
 def test_input_augmentation_kernel_and_plumbing():

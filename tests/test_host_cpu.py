@@ -162,6 +162,44 @@ def test_pad_collate_and_synthetic_dataset():
         pad_collate([])
 
 
+def test_harness_matches_reference_generated_fixture():
+    """tests/golden/harness.npz was recorded by make_golden.py from the reference's OWN interpolate_schedule
+    (experiment.py:14-34) and pad_collate (dataset.py:30-49) -- cut out of the source with ast, no Lightning import --
+    on the reference's own YAMLs, plus torch's OneCycleLR / CosineAnnealingLR with the YAMLs' parameters
+    (experiment.py:176-197).  This repo's host mirror must reproduce all of it."""
+    from experiment import interpolate_schedule, LRPolicy
+    from dataset import pad_collate
+    g = load_golden("harness")
+    for stem in ("stage1_ae", "stage2_vq"):
+        cfg = yaml.safe_load(open(os.path.join(PKG, "configs", stem + ".yaml")))
+        sched = cfg["exp_params"].get("schedules", {}) or {}
+        keys = [str(k) for k in g[f"{stem}_sched_keys"]]
+        assert sorted(sched.keys()) == keys
+        for e in range(201):
+            row = interpolate_schedule(sched, e)
+            assert sorted(row.keys()) == keys
+            got = np.array([row[k] for k in keys])
+            assert np.array_equal(got, g[f"{stem}_sched_vals"][:, e]), (stem, e)
+        lr0, epochs, spe, pct, div, fdiv = g[f"{stem}_onecycle_cfg"]
+        assert float(cfg["exp_params"]["LR"]) == lr0
+        pol = LRPolicy("onecycle", lr0, max_epochs=int(epochs), steps_per_epoch=int(spe), pct_start=pct, div_factor=div,
+                       final_div=fdiv)
+        for i in range(int(epochs * spe)):
+            lr, b1 = pol.current()
+            assert lr == pytest.approx(g[f"{stem}_onecycle"][0, i], rel=1e-12, abs=1e-18)
+            assert b1 == pytest.approx(g[f"{stem}_onecycle"][1, i], rel=1e-12)
+            pol.on_step()
+        pol = LRPolicy("cosine", lr0, max_epochs=12)
+        for i in range(12):
+            assert pol.current()[0] == pytest.approx(g[f"{stem}_cosine"][i], rel=1e-9)
+            pol.on_epoch()
+    gen = torch.Generator().manual_seed(4711)
+    items = [torch.randn(int(n), 6, generator=gen) for n in g["collate_lens"]]
+    x, mask = pad_collate(items)
+    assert torch.equal(x, torch.from_numpy(g["collate_x"])) and torch.equal(mask, torch.from_numpy(g["collate_mask"]))
+    assert x.dtype == torch.float32 and mask.dtype == torch.bool and int(g["collate_empty_raises"]) == 1
+
+
 class _CpuStandIn:
     """Test-only stand-in with the harness-facing interface of models.VQVAE, computing with the oracle.
     Exists so the harness (schedules, LR policy, checkpoints, epoch hooks) can be exercised without a GPU."""
