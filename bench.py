@@ -158,7 +158,7 @@ def main():
         tot_f = sum(v[2] for v in prof.values())
         dom = max(prof, key=lambda k: prof[k][1])            # the instantiation with the largest summed time
         n, t, f = prof[dom]
-        kname = "gemm_f32_mfma<%s, %s, 32, %d>" % (("true" if dom[0] else "false"), ("true" if dom[1] else "false"), dom[2])
+        kname = L.gemm_kernel_name(dom)
         traffic = None
         try:   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")))
@@ -167,7 +167,7 @@ def main():
                     traffic = d["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
-        per_kernel = {"gemm_f32_mfma<%s, %s, 32, %d>" % (("true" if k[0] else "false"), ("true" if k[1] else "false"), k[2]):
+        per_kernel = {L.gemm_kernel_name(k):
                       {"launches_per_step": v[0] // 2, "avg_launch_us": round(v[1] / v[0] * 1e6, 2),
                        "achieved": round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(f / t / 1e12, 2),

@@ -62,11 +62,13 @@ int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, con
 /* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
  * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads);
  * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier; bit 6 = no skinny-shape
- * streaming kernels (everything on the MFMA tile kernel) */
+ * streaming kernels (everything on the MFMA tile kernel); bit 7 = no 256x128 LDS-DMA kernel (everything that tiles
+ * evenly stays on the 128x128 register-staged kernel) */
 int vqh_gemm_set_flags(int flags);
 
 /* Live timing of the GEMM main kernels with HIP events on their launch stream (bench.py's roofline figure):
- * begin(), run eager (non-captured) steps, end(out) with out = double[4][9][3]: for operand layout (a_kcontig*2 +
+ * begin(), run eager (non-captured) steps, end(out) with out = double[2][4][9][3]: for kernel family (0 = gemm_f32_mfma,
+ * the 128x128 register-staged tile; 1 = gemm_f32_dma, the 256x128 LDS-DMA tile), operand layout (a_kcontig*2 +
  * b_kcontig) and kernel template MODE+1 (0 = generic kernel, 1.. = epilogue-specialised): launches, kernel seconds,
  * sum of 2*M*N*K.  The split-K reduce launch is not inside the bracket. */
 int vqh_gemm_profile_begin(void);

@@ -669,12 +669,17 @@ __global__ __launch_bounds__(256) void skinny_m_kernel(const float* __restrict__
     }
 }
 
+#include "gemm_dma.inc"
+
 // ---- live per-kernel timing (bench.py): hipEvents around each main-kernel launch, on the launch stream ----------
 struct ProfRec { int slot; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 constexpr int PROF_MODES = 9;                       // template MODE -1..7 -> column MODE+1
-inline int prof_slot(bool a_kc, bool b_kc, int mode_t) { return ((a_kc ? 2 : 0) + (b_kc ? 1 : 0)) * PROF_MODES + mode_t + 1; }
+constexpr int PROF_FAMILIES = 2;                    // 0 = gemm_f32_mfma (128x128 tile), 1 = gemm_f32_dma (256x128 tile)
+inline int prof_slot(bool a_kc, bool b_kc, int mode_t, int family = 0) {
+    return (family * 4 + (a_kc ? 2 : 0) + (b_kc ? 1 : 0)) * PROF_MODES + mode_t + 1;
+}
 
 template <bool A_KC, bool B_KC, int BKT, int MODE = -1>
 int launch(const GemmArgs& g, int splits, hipStream_t stream) {
@@ -713,10 +718,46 @@ int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     return VQH_OK;
 }
 
+template <bool A_KC, bool B_KC, int MODE = -1>
+int launch_dma(const GemmArgs& g, int splits, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma<A_KC, B_KC, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, dma::LDS_BYTES);
+        if (e != hipSuccess) {
+            vqh_set_error(hipGetErrorString(e));
+            return VQH_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid((g.M / dma::TBM) * (g.N / dma::TBN), 1, splits);
+    ProfRec rec{};
+    if (g_prof_on) {
+        rec.slot = prof_slot(A_KC, B_KC, MODE, 1);
+        rec.flops = 2.0 * g.M * g.N * g.K;
+        if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess ||
+            hipEventRecord(rec.e0, stream) != hipSuccess) {
+            vqh_set_error("vqh_gemm: profiling events failed");
+            return VQH_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((gemm_f32_dma<A_KC, B_KC, MODE>), grid, dim3(256), dma::LDS_BYTES, stream, g);
+    VQH_LAUNCH_CHECK();
+    if (g_prof_on) {
+        if (hipEventRecord(rec.e1, stream) != hipSuccess) {
+            vqh_set_error("vqh_gemm: profiling events failed");
+            return VQH_ERR_LAUNCH;
+        }
+        g_prof.push_back(rec);
+    }
+    return VQH_OK;
+}
+
 }  // namespace
 
 // Timing of every GEMM main-kernel launch between begin and end (not under stream capture).  end() synchronises
-// the recorded events and fills out[4][9][3]: per (operand layout a_kc*2+b_kc, template MODE+1) the number of
+// the recorded events and fills out[2][4][9][3]: per (kernel family 0 = gemm_f32_mfma / 1 = gemm_f32_dma, operand layout
+// a_kc*2+b_kc, template MODE+1) the number of
 // launches, the summed kernel seconds and the summed 2*M*N*K.  The split-K reduce launch is outside the bracket.
 extern "C" int vqh_gemm_profile_begin(void) {
     g_prof.clear();
@@ -726,7 +767,7 @@ extern "C" int vqh_gemm_profile_begin(void) {
 extern "C" int vqh_gemm_profile_end(double* out) {
     g_prof_on = false;
     if (out)
-        for (int i = 0; i < 4 * PROF_MODES * 3; ++i) out[i] = 0.0;
+        for (int i = 0; i < PROF_FAMILIES * 4 * PROF_MODES * 3; ++i) out[i] = 0.0;
     int rc = VQH_OK;
     for (ProfRec& r : g_prof) {
         float ms = 0.f;
@@ -829,6 +870,62 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
                 return rc2;
             }
         }
+    }
+
+    // ---- large-tile LDS-DMA kernel (gemm_dma.inc) for everything that tiles evenly: all the Linear layers of the model
+    if (!(g_gemm_flags & 128) && (M % dma::TBM) == 0 && (N % dma::TBN) == 0 && (K % dma::TBK) == 0 && K >= dma::TBK && g.vecA &&
+        g.vecB && g.vecC && (!rowsum || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0)) {
+        const int tiles_d = (M / dma::TBM) * (N / dma::TBN);
+        int splits_d = 1;
+        if (workspace && mode == EPI_LINEAR && tiles_d < 192 && K >= 8 * dma::TBK) {
+            splits_d = 256 / tiles_d;                   // one resident workgroup per CU: a single round, no tail
+            const int max_by_k = K / (4 * dma::TBK);
+            if (splits_d > max_by_k) splits_d = max_by_k;
+            const long long per = (long long)M * N + (rowsum ? M : 0);
+            if ((long long)splits_d * per > workspace_floats) splits_d = (int)(workspace_floats / per);
+            if (splits_d < 2) splits_d = 1;
+        }
+        int kchunk_d = ((K + splits_d - 1) / splits_d + dma::TBK - 1) / dma::TBK * dma::TBK;
+        splits_d = (K + kchunk_d - 1) / kchunk_d;
+        if (tiles_d * splits_d >= 96) {                 // enough workgroups to be worth a 256-row tile
+            g.kchunk = kchunk_d;
+            if (splits_d > 1) {
+                g.ws = workspace;
+                if (rowsum) g.rowsum_ws = workspace + (size_t)splits_d * M * N;
+            }
+            int rc;
+            if (a_kcontig && b_kcontig) {
+                if (splits_d == 1 && mode == EPI_DROP_RESID) rc = launch_dma<true, true, EPI_DROP_RESID>(g, splits_d, stream);
+                else if (splits_d == 1 && mode == EPI_RELU_DROP) rc = launch_dma<true, true, EPI_RELU_DROP>(g, splits_d, stream);
+                else if (splits_d == 1 && mode == EPI_GELU) rc = launch_dma<true, true, EPI_GELU>(g, splits_d, stream);
+                else if (mode == EPI_LINEAR) rc = launch_dma<true, true, EPI_LINEAR>(g, splits_d, stream);
+                else rc = launch_dma<true, true>(g, splits_d, stream);
+            } else if (a_kcontig && !b_kcontig) {
+                if (splits_d == 1 && mode == EPI_MUL_POSMASK) rc = launch_dma<true, false, EPI_MUL_POSMASK>(g, splits_d, stream);
+                else if (splits_d == 1 && mode == EPI_MUL_GELUGRAD) rc = launch_dma<true, false, EPI_MUL_GELUGRAD>(g, splits_d, stream);
+                else if (mode == EPI_LINEAR) rc = launch_dma<true, false, EPI_LINEAR>(g, splits_d, stream);
+                else rc = launch_dma<true, false>(g, splits_d, stream);
+            } else if (!a_kcontig && b_kcontig) {
+                if (mode == EPI_LINEAR) rc = launch_dma<false, true, EPI_LINEAR>(g, splits_d, stream);
+                else rc = launch_dma<false, true>(g, splits_d, stream);
+            } else {
+                if (mode == EPI_LINEAR) rc = launch_dma<false, false, EPI_LINEAR>(g, splits_d, stream);
+                else rc = launch_dma<false, false>(g, splits_d, stream);
+            }
+            if (rc != VQH_OK) return rc;
+            if (splits_d > 1) {
+                const size_t total = (size_t)M * N;
+                int blocks = (int)((total / 4 + 255) / 256);
+                if (blocks > 4096) blocks = 4096;
+                if (rowsum && blocks < (M + 255) / 256) blocks = (M + 255) / 256;
+                hipLaunchKernelGGL(splitk_reduce_vec, dim3(blocks), dim3(256), 0, stream, workspace, splits_d, M, N, C, ldc, bias,
+                                   beta, g.rowsum_ws, rowsum);
+                VQH_LAUNCH_CHECK();
+            }
+            return VQH_OK;
+        }
+        g.ws = nullptr;
+        g.rowsum_ws = nullptr;
     }
 
     // split-K when the output has too few tiles to fill 256 CUs (weight gradients: K = B*L rows).

@@ -109,25 +109,36 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, mode=EPI_LIN
 
 
 def gemm_profile(fn):
-    """Run fn() with the library's per-launch GEMM timing on; returns {(a_kc, b_kc, MODE): (launches, seconds, flops)}
-    keyed like the kernel's template arguments gemm_f32_mfma<a_kc, b_kc, 32, MODE>."""
+    """Run fn() with the library's per-launch GEMM timing on; returns {(family, a_kc, b_kc, MODE): (launches, seconds, flops)}
+    keyed like the kernels' template arguments: family 0 = gemm_f32_mfma<a_kc, b_kc, 32, MODE> (128x128 tile),
+    family 1 = gemm_f32_dma<a_kc, b_kc, MODE> (256x128 tile, LDS-DMA)."""
     import ctypes
     lib().vqh_gemm_profile_begin()
     try:
         fn()
         torch.cuda.synchronize()
     finally:
-        out = (ctypes.c_double * (4 * 9 * 3))()
+        out = (ctypes.c_double * (2 * 4 * 9 * 3))()
         rc = lib().vqh_gemm_profile_end(ctypes.cast(out, ctypes.c_void_p))
     if rc != 0:
         raise VqhError(f"vqh_gemm_profile_end failed: {lib().vqh_last_error().decode()}")
     res = {}
-    for lay in range(4):
-        for mc in range(9):
-            n, t, f = out[(lay * 9 + mc) * 3:(lay * 9 + mc) * 3 + 3]
-            if n > 0:
-                res[(lay >> 1, lay & 1, mc - 1)] = (int(n), t, f)
+    for fam in range(2):
+        for lay in range(4):
+            for mc in range(9):
+                o = ((fam * 4 + lay) * 9 + mc) * 3
+                n, t, f = out[o:o + 3]
+                if n > 0:
+                    res[(fam, lay >> 1, lay & 1, mc - 1)] = (int(n), t, f)
     return res
+
+
+def gemm_kernel_name(key):
+    fam, a_kc, b_kc, mode = key
+    tf = lambda b: "true" if b else "false"
+    if fam == 0:
+        return "gemm_f32_mfma<%s, %s, 32, %d>" % (tf(a_kc), tf(b_kc), mode)
+    return "gemm_f32_dma<%s, %s, %d>" % (tf(a_kc), tf(b_kc), mode)
 
 
 def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws):

@@ -48,7 +48,11 @@ def rel(a, b):
 @pytest.mark.parametrize("akc,bkc,M,N,K", [(1, 1, 257, 96, 130), (1, 0, 200, 64, 77), (0, 0, 64, 48, 1000),
                                             (0, 1, 33, 65, 129), (1, 1, 1024, 512, 512), (1, 1, 111, 6, 64), (1, 1, 5, 3, 0),
                                             # skinny shapes (reconstruction heads): streaming kernels behind the same entry point
-                                            (1, 1, 1000, 3, 512), (1, 1, 257, 8, 64), (1, 0, 1000, 512, 3), (1, 0, 77, 64, 8)])
+                                            (1, 1, 1000, 3, 512), (1, 1, 257, 8, 64), (1, 0, 1000, 512, 3), (1, 0, 77, 64, 8),
+                                            # evenly tiled shapes: the 256x128 LDS-DMA kernel, all four operand layouts,
+                                            # one / several K-steps, odd K-step counts
+                                            (1, 1, 4096, 768, 160), (1, 0, 4096, 768, 160), (0, 1, 4096, 768, 96), (0, 0, 4096, 768, 32),
+                                            (1, 1, 8192, 512, 512), (1, 0, 2560, 1280, 64), (0, 0, 3072, 1024, 224)])
 def test_gemm_layouts(akc, bkc, M, N, K):
     L = _hip()
     torch.manual_seed(M + N + K)
@@ -62,7 +66,8 @@ def test_gemm_layouts(akc, bkc, M, N, K):
     assert rel(C, ref) < 2e-6
 
 
-@pytest.mark.parametrize("rows,n_out,k_in", [(1000, 96, 130), (4096, 512, 256), (1000, 3, 512), (300, 6, 64), (16384, 3, 512)])
+@pytest.mark.parametrize("rows,n_out,k_in", [(1000, 96, 130), (4096, 512, 256), (1000, 3, 512), (300, 6, 64), (16384, 3, 512),
+                                              (16384, 512, 512), (8192, 1536, 512), (4000, 256, 128)])
 def test_gemm_wgrad_weight_and_bias_gradients(rows, n_out, k_in):
     """dW = dY^T X and db = column sums of dY in one entry point (split-K slabs, fused row sums, skinny outputs), with
     and without accumulation into existing gradients."""
@@ -127,6 +132,54 @@ def test_gemm_epilogues_and_dropout_determinism():
     rng2 = torch.tensor([1234, 8], device=DEV, dtype=torch.int64)   # next step -> different mask
     L.call("vqh_dropout_bwd", ones, out2.view(-1), M * N, rng2, 5, p)
     assert float((out2 != keep).float().mean()) > 0.05
+
+
+@pytest.mark.parametrize("flags", [1, 1 | 128])
+def test_gemm_epilogues_on_evenly_tiled_shapes(flags):
+    """The fused epilogues on a shape the 256x128 LDS-DMA kernel takes (flags bit 7 forces the 128x128 kernel: both must
+    give the same answers, dropout masks included)."""
+    L = _hip()
+    torch.manual_seed(7)
+    M, N, K = 2560, 1280, 96
+    X, W, b = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV) / 8, torch.randn(N, device=DEV)
+    Wt = W.t().contiguous()
+    R = torch.randn(M, N, device=DEV)
+    lin = X.double() @ W.double().t() + b.double()
+    rng = torch.tensor([4321, 9], device=DEV, dtype=torch.int64)
+    old = L.lib().vqh_gemm_set_flags(flags)
+    try:
+        out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        L.gemm(1, 1, M, N, K, X, K, W, K, out, N, bias=b)
+        assert rel(out, lin) < 2e-6
+        L.gemm(1, 1, M, N, K, X, K, W, K, out, N, bias=b, mode=L.EPI_GELU, aux_out=aux, ldaux=N)
+        assert rel(aux, lin) < 2e-6 and rel(out, torch.nn.functional.gelu(lin)) < 2e-6
+        L.gemm(1, 1, M, N, K, X, K, W, K, out, N, bias=b, mode=L.EPI_SIGMOID)
+        assert rel(out, torch.sigmoid(lin)) < 2e-6
+        p = 0.1
+        ones, keep = torch.ones(M * N, device=DEV), torch.empty(M * N, device=DEV)
+        L.call("vqh_dropout_bwd", ones, keep, M * N, rng, 5, p)
+        keep = keep.view(M, N).double()
+        L.gemm(1, 1, M, N, K, X, K, W, K, out, N, bias=b, mode=L.EPI_DROP_RESID, aux_in=R, ldaux=N, rng=rng, site=5, p=p)
+        assert rel(out, lin * keep + R.double()) < 2e-6
+        L.gemm(1, 1, M, N, K, X, K, W, K, out, N, bias=b, mode=L.EPI_RELU_DROP, rng=rng, site=5, p=p)
+        assert rel(out, torch.relu(lin) * keep) < 2e-6
+        # dgrad forms: dX[M, K'] = dY[M, N'] . W[N', K'] with the masks of the forward
+        dY = torch.randn(M, K, device=DEV)                      # reuse sizes: [M, K] . Wt^T?  -> out2 [M, N] = dY . Wt[K, N]
+        out2 = torch.empty(M, N, device=DEV)
+        prod = dY.double() @ Wt.double()
+        L.gemm(1, 0, M, N, K, dY, K, Wt, N, out2, N, mode=L.EPI_MUL_POSMASK, aux_in=R, ldaux=N, p=p)
+        scale = 1.0 / (1.0 - round(p * 65536) / 65536.0)
+        assert rel(out2, prod * (R.double() > 0) * scale) < 2e-6
+        L.gemm(1, 0, M, N, K, dY, K, Wt, N, out2, N, mode=L.EPI_MUL_GELUGRAD, aux_in=R, ldaux=N)
+        rd = R.double().cpu().requires_grad_(True)
+        torch.nn.functional.gelu(rd).sum().backward()
+        assert rel(out2, prod.cpu() * rd.grad) < 5e-6
+        C0 = torch.randn(M, N, device=DEV)
+        C1 = C0.clone()
+        L.gemm(1, 0, M, N, K, dY, K, Wt, N, C1, N, beta=1.0)
+        assert rel(C1, C0.double() + prod) < 2e-6
+    finally:
+        L.lib().vqh_gemm_set_flags(old)
 
 
 def test_layernorm_forward_backward():

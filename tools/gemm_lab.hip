@@ -1,0 +1,453 @@
+// GEMM lab (diagnostic, not product): candidate fp32-MFMA tile designs timed against the shipped kernel (vqh_gemm from
+// libvqvae_hip.so) in ONE process, interleaved rounds, random data (guide rules 24/25).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_lab.hip -o tools/_build/gemm_lab -ldl
+//   tools/_build/gemm_lab [M N K]...
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <array>
+#include <type_traits>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));  \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------------
+// v2: NT product C[M,N] = A[M,K] . B[N,K]^T, both operands k-contiguous.
+//   macro tile BM x BN x 32, WAVES_M x WAVES_N waves, each WM x WN (multiples of 32) of 32x32 MFMA blocks
+//   global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The LDS image of a tile is
+//   [rows][32 floats] = 128-B rows, lane-linear per DMA instruction (8 rows x 128 B); bank conflicts of the k-permuted
+//   ds_read_b128 fragments are removed by an XOR swizzle of the 16-B chunk index with (row >> 1) & 7, applied on the
+//   SOURCE address of the DMA and on the fragment read (same involution).
+//   3-stage ring; ONE barrier per K-step placed in the MIDDLE of the step: before it every wave waits for its own DMAs of
+//   tile kt+1 (issued a full step earlier), after it tile kt+1 is readable by everyone and tile kt-1's buffer is free, so
+//   the DMAs of tile kt+2 are issued there.  The first fragments of tile kt+1 are prefetched under the last MFMAs of kt.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+struct V2Cfg {
+    static constexpr int BM = WM * WAVES_M, BN = WN * WAVES_N, BK = 32;
+    static constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
+    static constexpr int STAGE_BYTES = (BM + BN) * BK * 4;
+    static constexpr int STAGES = 3;
+    static constexpr int LDS_BYTES = STAGE_BYTES * STAGES;
+    static constexpr int DMA_PER_STAGE = (BM + BN) / 8;        // wave-instructions (8 rows each)
+    static constexpr int DMA_PER_WAVE = DMA_PER_STAGE / NW;
+    static constexpr int MI = WM / 32, NJ = WN / 32;
+};
+
+__device__ __forceinline__ void glds16(const float* gptr, unsigned lds_byte_addr_uniform) {
+    // LDS-DMA: 64 lanes x 16 B land at lds_byte_addr_uniform + lane * 16
+    __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte_addr_uniform, 16, 0, 0);
+}
+
+__device__ unsigned long long* g_stamps = nullptr;      // diagnostic: [block][8] = {t0, after prologue, after loop, end} x {cycles, realtime}
+#define STAMP(slot)                                                                                     \
+    if (EPI >= 2 && lane == 0 && wave == 0) {                                                           \
+        g_stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();                       \
+        g_stamps[(size_t)blockIdx.x * 8 + 4 + (slot)] = __builtin_amdgcn_s_memrealtime();              \
+    }
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_v2_nt(const float* __restrict__ A, const float* __restrict__ B,
+                                                                       float* __restrict__ C, int M, int N, int K, int lda,
+                                                                       int ldb, int ldc) {
+    using Cf = V2Cfg<WM, WN, WAVES_M, WAVES_N>;
+    constexpr int BM = Cf::BM, BN = Cf::BN, BK = Cf::BK, NW = Cf::NW, MI = Cf::MI, NJ = Cf::NJ;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, h = lane >> 5;
+    STAMP(0)
+
+    // XCD-aware tile order: consecutive linear ids go to different XCDs; give each XCD a contiguous run of tiles
+    const int tiles_n = N / BN, ntile = gridDim.x;
+    int tile;
+    {
+        const int lin = blockIdx.x, q = ntile >> 3, r = ntile & 7, x = lin & 7, j = lin >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int nk = K / BK;
+
+    // ---- DMA source pointers: instruction j = wave + NW * i covers rows 8j .. 8j+7 of the stacked [A rows | B rows] image
+    const float* src[Cf::DMA_PER_WAVE];
+    unsigned dst[Cf::DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < Cf::DMA_PER_WAVE; ++i) {
+        const int j = wave + NW * i;
+        const int R = j * 8 + (lane >> 3);            // row in the stacked image
+        const int p = lane & 7;
+        const int c = p ^ ((R >> 1) & 7);             // chunk of the row that lands at position p
+        if (j * 8 < BM) src[i] = A + (size_t)(m0 + R) * lda + c * 4;
+        else src[i] = B + (size_t)(n0 + R - BM) * ldb + c * 4;
+        dst[i] = j * 1024;                            // wave-uniform byte offset inside a stage
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;  // LDS byte address of the ring (low 32 bits of the shared pointer)
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned sb = lds0 + stage * Cf::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < Cf::DMA_PER_WAVE; ++i) glds16(src[i] + (size_t)kt * BK, sb + dst[i]);
+    };
+
+    // ---- fragment addresses: row base + swizzled chunk offset for t = 0..3 (k = 8t + 4h + e)
+    const int sw = (l31 >> 1) & 7;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned ch = (unsigned)(((2 * t + h) ^ sw) * 16);
+        offA[t] = (unsigned)((wm * WM + l31) * 128) + ch;
+        offB[t] = (unsigned)((BM + wn * WN + l31) * 128) + ch;
+    }
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int ABL = (EPI >= 2) ? (EPI - 2) / 4 : 0;
+    auto read_frags = [&](int stage, int t, f32x4 (&fa)[MI], f32x4 (&fb)[NJ]) {
+        if (ABL & 4) {       // no LDS reads: keep whatever is in the registers, but make them opaque so nothing folds
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[j]));
+            return;
+        }
+        const unsigned char* sb = smem + stage * Cf::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(sb + offA[t] + i * 32 * 128);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4*>(sb + offB[t] + j * 32 * 128);
+    };
+    auto mfma_step = [&](const f32x4 (&fa)[MI], const f32x4 (&fb)[NJ]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed and visible
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cf::DMA_PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    STAMP(1)
+    constexpr bool ILV = (EPI >= 2) ? (((EPI - 2) / 4) & 8) != 0 : (EPI == 1 || EPI == 0) ? false : false;
+    // one sub-step with everything interleaved at MFMA granularity: 32 (4w) / 16 (8w) MFMAs of fragment set `c`, the
+    // MI + NJ fragment reads of the next sub-step (one after every 4th MFMA), and DMA instructions [v0, v1) of tile `kt_d`
+    auto sub_ilv = [&](f32x4 (&ca)[MI], f32x4 (&cb)[NJ], f32x4 (&na)[MI], f32x4 (&nb)[NJ], int rstage, auto rt_c, auto v0_c,
+                       auto v1_c, int kt_d, int dstage) {
+        constexpr int rt = decltype(rt_c)::value, V0 = decltype(v0_c)::value, V1 = decltype(v1_c)::value;
+        const unsigned char* sb = smem + rstage * Cf::STAGE_BYTES;
+        const unsigned dsb = lds0 + dstage * Cf::STAGE_BYTES;
+        constexpr int NM = 4 * MI * NJ;
+        constexpr int GAP = NM / (MI + NJ + 1) > 0 ? NM / (MI + NJ + 1) : 1;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int e = m / (MI * NJ), i = (m / NJ) % MI, j = m % NJ;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i][e], cb[j][e], acc[i][j], 0, 0, 0);
+            if (!(ABL & 4) && (m % GAP) == 0 && m / GAP < MI + NJ) {
+                const int d = m / GAP;
+                if (d < MI) na[d] = *reinterpret_cast<const f32x4*>(sb + offA[rt] + d * 32 * 128);
+                else nb[d - MI] = *reinterpret_cast<const f32x4*>(sb + offB[rt] + (d - MI) * 32 * 128);
+            }
+            if (!(ABL & 2) && (m % GAP) == GAP / 2 && V0 + m / GAP < V1) {
+                const int v = V0 + m / GAP;
+                glds16(src[v] + (size_t)kt_d * BK, dsb + dst[v]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (!(ABL & 4) && (m % GAP) == 0 && m / GAP < MI + NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (!(ABL & 2) && (m % GAP) == GAP / 2 && V0 + m / GAP < V1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    };
+    f32x4 fa[2][MI], fb[2][NJ];
+    if (ABL & 4) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[q][i] = f32x4{1.f + lane, 2.f, 3.f, 4.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[q][j] = f32x4{0.5f, 0.25f * lane, 1.f, 2.f};
+        }
+    }
+    read_frags(0, 0, fa[0], fb[0]);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = (stage == 2) ? 0 : stage + 1;
+        const int nx2 = (nxt == 2) ? 0 : nxt + 1;
+        if (ILV) {
+            constexpr int HALF = Cf::DMA_PER_WAVE / 2;
+            using I0 = std::integral_constant<int, 0>;
+            using IH = std::integral_constant<int, HALF>;
+            using IF = std::integral_constant<int, Cf::DMA_PER_WAVE>;
+            sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 1>{}, I0{}, I0{}, 0, 0);
+            sub_ilv(fa[1], fb[1], fa[0], fb[0], stage, std::integral_constant<int, 2>{}, I0{}, I0{}, 0, 0);
+            if (!(ABL & 1)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            // past the end the last tile is simply re-loaded into the free buffer (never read): no tail special case
+            const int ktd = min(kt + 2, nk - 1);
+            sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 3>{}, I0{}, IH{}, ktd, nx2);
+            sub_ilv(fa[1], fb[1], fa[0], fb[0], nxt, I0{}, IH{}, IF{}, ktd, nx2);
+            stage = nxt;
+            continue;
+        }
+        // sub-steps 0, 1
+        read_frags(stage, 1, fa[1], fb[1]);
+        mfma_step(fa[0], fb[0]);
+        read_frags(stage, 2, fa[0], fb[0]);
+        mfma_step(fa[1], fb[1]);
+        // middle of the step: tile kt+1 complete for everyone, buffer of tile kt-1 free
+        if (!(ABL & 1)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!(ABL & 2) && kt + 2 < nk) issue_tile(kt + 2, nx2);
+        // sub-steps 2, 3
+        read_frags(stage, 3, fa[1], fb[1]);
+        mfma_step(fa[0], fb[0]);
+        if (kt + 1 < nk) read_frags(nxt, 0, fa[0], fb[0]);
+        mfma_step(fa[1], fb[1]);
+        stage = nxt;
+    }
+
+    // ---- epilogue
+    if (EPI >= 2) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        asm volatile("s_nop 0" ::"v"(s));
+        STAMP(2)
+        if (s == 123.456f) C[0] = s;
+        return;
+    }
+    if (EPI == 0) {          // none: keep the accumulators alive
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 123.456f) C[0] = s;
+        return;
+    }
+    // through LDS, one 32 x WN block row of the wave at a time -> 16-byte stores of whole 256-B row segments
+    __builtin_amdgcn_s_barrier();                     // every wave is done reading operand tiles
+    constexpr int EP_LD = WN + 4;
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                ep[row * EP_LD + j * 32 + l31] = acc[i][j][r];
+            }
+        // wave-private region: no barrier needed, but the LDS writes must have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int LPR = WN / 4;                   // lanes per row
+        constexpr int RPP = 64 / LPR;                 // rows per pass
+#pragma unroll
+        for (int q = 0; q < 32 / RPP; ++q) {
+            const int row = q * RPP + lane / LPR, c4 = (lane % LPR) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + c4);
+            *reinterpret_cast<f32x4*>(C + (size_t)(m0 + wm * WM + i * 32 + row) * ldc + n0 + wn * WN + c4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+typedef int (*vqh_gemm_fn)(int, int, int, int, int, const float*, int, const float*, int, float*, int, const float*, int,
+                           const float*, float*, int, float, const unsigned long long*, unsigned, float, float*, long long,
+                           hipStream_t);
+
+static void fill(std::vector<float>& v, unsigned seed) {
+    unsigned s = seed;
+    for (auto& x : v) {
+        s = s * 1664525u + 1013904223u;
+        x = ((s >> 8) * (1.0f / 8388608.0f)) - 1.0f;
+    }
+}
+
+struct Variant {
+    const char* name;
+    void (*run)(const float*, const float*, float*, int, int, int, hipStream_t);
+    bool (*ok)(int, int, int);
+};
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
+static void run_v2(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t st) {
+    using Cf = V2Cfg<WM, WN, WAVES_M, WAVES_N>;
+    static bool attr = false;
+    auto kern = gemm_v2_nt<WM, WN, WAVES_M, WAVES_N, EPI>;
+    if (!attr) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES));
+        attr = true;
+    }
+    const int tiles = (M / Cf::BM) * (N / Cf::BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(Cf::NT), Cf::LDS_BYTES, st, A, B, C, M, N, K, K, K, N);
+}
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+static bool ok_v2(int M, int N, int K) {
+    using Cf = V2Cfg<WM, WN, WAVES_M, WAVES_N>;
+    return M % Cf::BM == 0 && N % Cf::BN == 0 && K % 32 == 0;
+}
+
+static vqh_gemm_fn g_ref = nullptr;
+static float* g_ws = nullptr;
+static void run_ref(const float* A, const float* B, float* C, int M, int N, int K, hipStream_t st) {
+    int rc = g_ref(1, 1, M, N, K, A, K, B, K, C, N, nullptr, 0, nullptr, nullptr, 0, 0.f, nullptr, 0, 0.f, g_ws, 64ll << 20, st);
+    if (rc) { fprintf(stderr, "vqh_gemm rc=%d\n", rc); exit(1); }
+}
+static bool ok_any(int, int, int) { return true; }
+
+int main(int argc, char** argv) {
+    std::vector<std::array<int, 3>> shapes;
+    for (int i = 1; i + 2 < argc; i += 3) shapes.push_back({atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2])});
+    if (shapes.empty()) shapes = {{16384, 512, 512}, {16384, 1536, 512}, {16384, 2048, 512}, {16384, 512, 2048}, {16384, 512, 1024}};
+    void* h = dlopen("pytorch-vae_amd/vqvae_hip/libvqvae_hip.so", RTLD_NOW);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+    g_ref = (vqh_gemm_fn)dlsym(h, "vqh_gemm");
+    CK(hipMalloc(&g_ws, (64ll << 20) * 4));
+    std::vector<Variant> vars = {
+        {"shipped 128x128 (2 WG/CU)", run_ref, ok_any},
+        {"v2 256x128 4w(128x64) full", run_v2<128, 64, 2, 2, 1>, ok_v2<128, 64, 2, 2>},
+        {"v2 256x128 4w(128x64) noepi", run_v2<128, 64, 2, 2, 0>, ok_v2<128, 64, 2, 2>},
+        {"v2 256x128 8w(64x64) full", run_v2<64, 64, 4, 2, 1>, ok_v2<64, 64, 4, 2>},
+        {"v2 256x128 8w(64x64) noepi", run_v2<64, 64, 4, 2, 0>, ok_v2<64, 64, 4, 2>},
+        {"v2 256x128 4w stamps noepi", run_v2<128, 64, 2, 2, 2>, ok_v2<128, 64, 2, 2>},
+        {"v2 256x128 8w stamps noepi", run_v2<64, 64, 4, 2, 2>, ok_v2<64, 64, 4, 2>},
+        {"4w stamps ILV", run_v2<128, 64, 2, 2, 2 + 4 * 8>, ok_v2<128, 64, 2, 2>},
+        {"8w stamps ILV", run_v2<64, 64, 4, 2, 2 + 4 * 8>, ok_v2<64, 64, 4, 2>},
+        {"4w stamps ILV -barrier", run_v2<128, 64, 2, 2, 2 + 4 * 9>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps ILV -dma", run_v2<128, 64, 2, 2, 2 + 4 * 10>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps ILV -lds", run_v2<128, 64, 2, 2, 2 + 4 * 12>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps ILV -barrier -dma", run_v2<128, 64, 2, 2, 2 + 4 * 11>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps ILV -barrier -dma -lds", run_v2<128, 64, 2, 2, 2 + 4 * 15>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps -barrier", run_v2<128, 64, 2, 2, 2 + 4 * 1>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps -dma", run_v2<128, 64, 2, 2, 2 + 4 * 2>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps -barrier -dma", run_v2<128, 64, 2, 2, 2 + 4 * 3>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps -lds", run_v2<128, 64, 2, 2, 2 + 4 * 4>, ok_v2<128, 64, 2, 2>},
+        {"4w stamps -barrier -dma -lds", run_v2<128, 64, 2, 2, 2 + 4 * 7>, ok_v2<128, 64, 2, 2>},
+        {"8w stamps -barrier -dma -lds", run_v2<64, 64, 4, 2, 2 + 4 * 7>, ok_v2<64, 64, 4, 2>},
+    };
+    unsigned long long* d_st;
+    CK(hipMalloc(&d_st, 8192 * 8 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    for (auto& sh : shapes) {
+        const int M = sh[0], N = sh[1], K = sh[2];
+        std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+        fill(hA, 1 + M + K);
+        fill(hB, 7 + N + K);
+        float *dA, *dB, *dC, *dR;
+        CK(hipMalloc(&dA, hA.size() * 4));
+        CK(hipMalloc(&dB, hB.size() * 4));
+        CK(hipMalloc(&dC, (size_t)M * N * 4));
+        CK(hipMalloc(&dR, (size_t)M * N * 4));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+        run_ref(dA, dB, dR, M, N, K, st);
+        CK(hipStreamSynchronize(st));
+        std::vector<float> hR((size_t)M * N), hC((size_t)M * N);
+        CK(hipMemcpy(hR.data(), dR, hR.size() * 4, hipMemcpyDeviceToHost));
+        printf("== M=%d N=%d K=%d  (%.2f GFLOP)\n", M, N, K, 2.0 * M * N * K / 1e9);
+        std::vector<std::vector<float>> times(vars.size());
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        for (size_t v = 0; v < vars.size(); ++v) {
+            if (!vars[v].ok(M, N, K)) continue;
+            CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
+            vars[v].run(dA, dB, dC, M, N, K, st);
+            CK(hipStreamSynchronize(st));
+            if (strstr(vars[v].name, "noepi") == nullptr) {
+                CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+                double worst = 0, scale = 0;
+                for (size_t i = 0; i < hC.size(); ++i) {
+                    worst = std::max(worst, (double)fabsf(hC[i] - hR[i]));
+                    scale = std::max(scale, (double)fabsf(hR[i]));
+                }
+                if (!(worst <= 2e-5 * scale)) printf("   !! %s: max|diff| %.3e (scale %.3e)\n", vars[v].name, worst, scale);
+            }
+        }
+        const int ROUNDS = 5, IT = 10;
+        for (int r = 0; r < ROUNDS; ++r)
+            for (size_t v = 0; v < vars.size(); ++v) {
+                if (!vars[v].ok(M, N, K)) continue;
+                vars[v].run(dA, dB, dC, M, N, K, st);
+                CK(hipEventRecord(e0, st));
+                for (int it = 0; it < IT; ++it) vars[v].run(dA, dB, dC, M, N, K, st);
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                times[v].push_back(ms / IT * 1e3f);
+            }
+        for (size_t v = 0; v < vars.size(); ++v) {
+            if (strstr(vars[v].name, "stamps") == nullptr || !vars[v].ok(M, N, K)) continue;
+            // the chip must be warm and loaded: 200 back-to-back launches, read the stamps of the last one
+            for (int it = 0; it < 200; ++it) vars[v].run(dA, dB, dC, M, N, K, st);
+            CK(hipStreamSynchronize(st));
+            const int nb = (M / 256) * (N / 128);
+            std::vector<unsigned long long> hs((size_t)nb * 8);
+            CK(hipMemcpy(hs.data(), d_st, hs.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> pro, loop, clk;
+            unsigned long long tmin = ~0ull, tmax = 0;
+            for (int b = 0; b < nb; ++b) {
+                const unsigned long long* q = &hs[(size_t)b * 8];
+                pro.push_back((double)(q[1] - q[0]));
+                loop.push_back((double)(q[2] - q[1]));
+                clk.push_back((double)(q[2] - q[0]) / (double)(q[6] - q[4]) * 100.0);     // MHz: cycles per 100 MHz tick
+                tmin = std::min(tmin, q[4]);
+                tmax = std::max(tmax, q[6]);
+            }
+            std::sort(pro.begin(), pro.end()); std::sort(loop.begin(), loop.end()); std::sort(clk.begin(), clk.end());
+            printf("   [%s] per-WG cycles: prologue med %.0f, loop med %.0f (min %.0f max %.0f) = %.0f per K-step; clock med %.0f MHz; "
+                   "first start -> last end %.1f us\n", vars[v].name, pro[nb / 2], loop[nb / 2], loop[0], loop[nb - 1],
+                   loop[nb / 2] / (K / 32), clk[nb / 2], (double)(tmax - tmin) / 100.0);
+        }
+        for (size_t v = 0; v < vars.size(); ++v) {
+            if (times[v].empty()) continue;
+            std::sort(times[v].begin(), times[v].end());
+            const float med = times[v][times[v].size() / 2], mn = times[v][0];
+            printf("   %-32s median %8.1f us %6.1f TF/s   best %8.1f us %6.1f TF/s\n", vars[v].name, med,
+                   2.0 * M * N * K / med / 1e6, mn, 2.0 * M * N * K / mn / 1e6);
+        }
+        CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR));
+    }
+    return 0;
+}

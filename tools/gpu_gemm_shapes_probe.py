@@ -19,4 +19,4 @@ tot = sum(v[1] for v in prof.values()) / R
 print(f"total GEMM main-kernel time/step {tot*1e3:.2f} ms")
 print("kernel <a_kc,b_kc,MODE>   n/step  us/launch  TF/s   ms/step")
 for k, (n, t, f) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-    print(f"{str(k):24s} {n//R:6d} {t/n*1e6:10.1f} {f/t/1e12:6.1f} {t/R*1e3:8.3f}")
+    print(f"{L.gemm_kernel_name(k):44s} {n//R:6d} {t/n*1e6:10.1f} {f/t/1e12:6.1f} {t/R*1e3:8.3f}")
