@@ -136,9 +136,19 @@ int vqh_attn_set_flags(int flags);
 /* ids of positions outside `valid` (bytes, 1 = valid) become -1, which the statistics entry points below ignore:
  * VectorQuantizerEMA.forward(mask=...) restricts the EMA statistics / usage histogram to valid positions (:192-205, :251-256) */
 int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long* out, int R, vqh_stream_t stream);
-/* VectorQuantizerEMA (models/vq_vae.py:19-283) */
+/* VectorQuantizerEMA (models/vq_vae.py:19-283).
+ * vqh_vq_nearest = distances + argmin (:183-188 / :238-244) without the R x K matrix: fp32 MFMA scores with top-2 tracking,
+ * rows inside the fp32 noise band re-evaluated in fp64 (first-minimum tie rule of torch.argmin).  For D = 8..256 (power
+ * of two) the codebook streams through LDS in 64-code tiles shared by 4 waves that keep their Z rows in registers.
+ * workspace_floats >= 3T + 4K + 2R + 3*nsplit*R + R/4 + 8 with T = smallest power of two >= 2K (>= 64), nsplit <= K/256 + 1 */
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
                    int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);
+/* diagnostic: bit 0 = always use the per-wave global-gather nearest kernel (round-1 form); returns the previous flags */
+int vqh_vq_set_flags(int flags);
+/* live timing of the nearest-neighbour main kernel with HIP events on its launch stream (bench.py --vq-only):
+ * begin(), eager calls, end(out) with out = double[3] = {launches, kernel seconds, sum of 2*R*K*D} */
+int vqh_vq_profile_begin(void);
+int vqh_vq_profile_end(double* out);
 int vqh_vq_gather(const float* E, int lde, const long long* idx, int idx_offset, const float* rows_in, int ldr,
                   float* zq_level, float* res_out, int R, int D, vqh_stream_t stream);
 int vqh_vq_finish(const float* zq_levels, int Q, const float* ze, int ldz, float* zq, float* zst, int R, int D,

@@ -11,6 +11,7 @@
 //   vqh_vq_ema_apply   ema <- d*ema + (1-d)*stat; E <- ema_emb / (ema_cnt + eps) for the WHOLE table (:85-89)
 //   vqh_vq_usage_stats perplexity / dead ratio / epoch accumulators (:201-220, :265-278)
 #include "common.h"
+#include <vector>
 
 namespace {
 
@@ -51,26 +52,50 @@ __global__ void code_hash_kernel(const float* __restrict__ E, int lde, int K, in
     for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
     if (lane == 0) hash[k] = h;
 }
-// one wave per code k: lanes scan the hashes of codes j < k, 64 at a time, in ascending order; the first hash match
-// that is a true row match (verified by the whole wave) is the canonical index.
-__global__ __launch_bounds__(256) void code_canon_kernel(const unsigned long long* __restrict__ hash,
-                                                         const float* __restrict__ E, int lde, int K, int D,
-                                                         int* __restrict__ canon) {
+// canon[k] in O(K): an open-addressing table keyed by the 64-bit row hash collects, per distinct hash, the LOWEST code
+// index (atomicMin: the result does not depend on the insertion order); a wave per code then verifies that row k really
+// equals that row (a hash collision of different rows leaves canon[k] = k, which is merely conservative: such a row
+// pair would be flagged ambiguous and settled exactly by the refinement).  Round 1 scanned all j < k per code (O(K^2):
+// 0.9 ms at K = 8192, every step).
+constexpr unsigned long long HASH_EMPTY = ~0ull;
+__global__ void canon_init_kernel(unsigned long long* __restrict__ keys, int* __restrict__ minidx, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T) { keys[i] = HASH_EMPTY; minidx[i] = 0x7fffffff; }
+}
+__global__ void canon_insert_kernel(const unsigned long long* __restrict__ hash, int K, unsigned long long* __restrict__ keys,
+                                    int* __restrict__ minidx, int T) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    unsigned long long hk = hash[k];
+    if (hk == HASH_EMPTY) hk = 0x1234567ull;
+    unsigned slot = (unsigned)(hk ^ (hk >> 29)) & (unsigned)(T - 1);
+    for (int probe = 0; probe < T; ++probe) {
+        const unsigned long long prev = atomicCAS(&keys[slot], HASH_EMPTY, hk);
+        if (prev == HASH_EMPTY || prev == hk) { atomicMin(&minidx[slot], k); return; }
+        slot = (slot + 1) & (unsigned)(T - 1);
+    }
+}
+__global__ __launch_bounds__(256) void canon_lookup_kernel(const unsigned long long* __restrict__ hash,
+                                                           const float* __restrict__ E, int lde, int K, int D,
+                                                           const unsigned long long* __restrict__ keys,
+                                                           const int* __restrict__ minidx, int T, int* __restrict__ canon) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= K) return;
-    const unsigned long long hk = hash[k];
+    unsigned long long hk = hash[k];
+    if (hk == HASH_EMPTY) hk = 0x1234567ull;
+    unsigned slot = (unsigned)(hk ^ (hk >> 29)) & (unsigned)(T - 1);
     int c = k;
-    for (int base = 0; base < k && c == k; base += 64) {
-        const int j = base + lane;
-        unsigned long long m = __ballot(j < k && hash[j] == hk);
-        while (m) {
-            const int jj = base + __ffsll((long long)m) - 1;
-            m &= m - 1;
-            bool same = true;
-            for (int i = lane; i < D; i += 64) same = same && (E[(size_t)jj * lde + i] == E[(size_t)k * lde + i]);
-            if (__all(same)) { c = jj; break; }
-        }
+    for (int probe = 0; probe < T; ++probe) {
+        const unsigned long long key = keys[slot];
+        if (key == hk) { c = minidx[slot]; break; }
+        if (key == HASH_EMPTY) break;
+        slot = (slot + 1) & (unsigned)(T - 1);
+    }
+    if (c != k) {                                    // wave-uniform: verify the rows are really identical
+        bool same = true;
+        for (int i = lane; i < D; i += 64) same = same && (E[(size_t)c * lde + i] == E[(size_t)k * lde + i]);
+        if (!__all(same)) c = k;
     }
     if (lane == 0) canon[k] = c;
 }
@@ -122,6 +147,132 @@ __global__ __launch_bounds__(64, 2) void vq_nearest_kernel(const float* __restri
                 }
             }
         }
+    }
+    // combine the two lane halves (same row, disjoint code subsets)
+    const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
+    const int oi = __shfl_xor(bidx, 32, 64), oc = __shfl_xor(bcan, 32, 64);
+    const bool dup = (ob == best) && (oc == bcan);
+    float fb, fs;
+    int fi;
+    if (ob < best || (ob == best && oi < bidx)) {
+        fb = ob; fi = oi; fs = dup ? fminf(second, os) : fminf(best, os);
+    } else {
+        fb = best; fi = bidx; fs = dup ? fminf(second, os) : fminf(ob, second);
+    }
+    if (rok && h == 0) {
+        const size_t o = (size_t)blockIdx.y * R + row;
+        pbest[o] = fb;
+        psecond[o] = fs;
+        pidx[o] = fi;
+    }
+}
+
+// LDS-staged form (D = 8 * NT8 <= 256): a workgroup of 4 waves owns 128 rows; every wave keeps ITS 32 rows of Z in
+// registers for the whole kernel (D/2 VGPRs per lane, the k-permuted B operand) and the codebook streams through LDS in
+// tiles of 64 codes shared by the 4 waves (register-staged, double buffered, padded rows: conflict-free ds_read_b128) --
+// the codebook is fetched once per 128 rows instead of once per 32, and never from a per-lane global gather.  The code
+// norms and canonical indices of a tile ride along in LDS.  Scores, top-2 tracking and tie rules are EXACTLY those of
+// vq_nearest_kernel (same MFMA order over k, same comparisons), so both kernels return identical partials.
+template <int NT8>
+__global__ __launch_bounds__(256, 2) void vq_nearest_lds_kernel(const float* __restrict__ Z, int ldz,
+                                                                const float* __restrict__ E, int lde,
+                                                                const float* __restrict__ enorm,
+                                                                const int* __restrict__ canon, float* __restrict__ pbest,
+                                                                float* __restrict__ psecond, int* __restrict__ pidx, int R,
+                                                                int K, int kchunk) {
+    constexpr int D = 8 * NT8, LDT = D + 4;
+    constexpr int CT = (NT8 >= 32) ? 32 : 64;            // codes per LDS tile (D = 256: 32, or the staging registers spill)
+    constexpr int TILE_F = CT * LDT;                          // floats per code tile
+    constexpr int CHUNKS = CT * (D / 4);                      // 16-byte chunks per tile
+    constexpr int LPT = (CHUNKS + 255) / 256;                 // chunk loads per thread
+    extern __shared__ __attribute__((aligned(16))) float vsm[];
+    auto tileb = [&](int b) { return vsm + b * TILE_F; };
+    auto nrm = [&](int b) { return vsm + 2 * TILE_F + b * CT; };
+    auto can = [&](int b) { return reinterpret_cast<int*>(vsm + 2 * TILE_F + 2 * CT) + b * CT; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 128 + wave * 32 + l31;
+    const bool rok = row < R;
+    const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+
+    f32x4 zf[NT8];
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+        zf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rok) zf[t] = *reinterpret_cast<const f32x4*>(Z + (size_t)row * ldz + 8 * t + 4 * h);
+    }
+    f32x4 stg[LPT];
+    float stg_n = 0.f;
+    int stg_c = 0;
+    auto load_tile = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int ch = tid + 256 * i;
+            const int code = c0 + ch / (D / 4);
+            stg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ch < CHUNKS && code < kend) stg[i] = *reinterpret_cast<const f32x4*>(E + (size_t)code * lde + (ch % (D / 4)) * 4);
+        }
+        if (tid < CT) {
+            const int code = c0 + tid;
+            stg_n = (code < kend) ? enorm[code] : 0.f;
+            stg_c = (code < kend) ? canon[code] : -1;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int ch = tid + 256 * i;
+            if (ch < CHUNKS) *reinterpret_cast<f32x4*>(tileb(buf) + (ch / (D / 4)) * LDT + (ch % (D / 4)) * 4) = stg[i];
+        }
+        if (tid < CT) { nrm(buf)[tid] = stg_n; can(buf)[tid] = stg_c; }
+    };
+
+    float best = INFINITY, second = INFINITY;
+    int bidx = 0x7fffffff, bcan = -1;
+    load_tile(kbeg);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = kbeg; c0 < kend; c0 += CT) {
+        const bool more = c0 + CT < kend;
+        if (more) load_tile(c0 + CT);
+        const float* tb = tileb(buf);
+        const float* nb = nrm(buf);
+        const int* cb = can(buf);
+#pragma unroll
+        for (int blk = 0; blk < CT / 32; ++blk) {
+            if (c0 + blk * 32 >= kend) break;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ep = tb + (blk * 32 + l31) * LDT + 4 * h;
+#pragma unroll
+            for (int t = 0; t < NT8; ++t) {
+                const f32x4 ef = *reinterpret_cast<const f32x4*>(ep + 8 * t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[j], zf[t][j], acc, 0, 0, 0);
+            }
+            // acc[r] = dot(E[c0 + 32 blk + kmap(r,h)], Z[row])
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = blk * 32 + kmap(r, h);
+                const int code = c0 + cl;
+                if (code < kend) {
+                    const float d = nb[cl] - 2.f * acc[r];
+                    if (d < best) {
+                        second = best;
+                        best = d;
+                        bidx = code;
+                        bcan = cb[cl];
+                    } else if (d < second) {
+                        if (!(d == best && cb[cl] == bcan)) second = d;    // an exact duplicate of the best is not a rival
+                    }
+                }
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
     // combine the two lane halves (same row, disjoint code subsets)
     const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
@@ -435,7 +586,43 @@ inline int blocks_for(long long n) {
 
 }  // namespace
 
-// workspace (floats): K code norms + R row norms + R best scores + nsplit*R*(best, second, index) + R/4 flag bytes
+// Live timing of the nearest-neighbour main kernel (bench.py --vq-only), like vqh_gemm_profile_*: begin(), eager calls,
+// end(out[3]) = {launches, kernel seconds, sum of 2*R*K*D}.
+namespace {
+struct VqProfRec { double flops; hipEvent_t e0, e1; };
+bool g_vq_prof_on = false;
+std::vector<VqProfRec> g_vq_prof;
+int g_vq_flags = 0;             // bit 0: force the per-wave global-gather kernel (round-1 form), for A/B runs and tests
+}  // namespace
+extern "C" int vqh_vq_set_flags(int flags) { const int old = g_vq_flags; g_vq_flags = flags; return old; }
+extern "C" int vqh_vq_profile_begin(void) {
+    g_vq_prof.clear();
+    g_vq_prof_on = true;
+    return VQH_OK;
+}
+extern "C" int vqh_vq_profile_end(double* out) {
+    g_vq_prof_on = false;
+    int rc = VQH_OK;
+    if (out) out[0] = out[1] = out[2] = 0.0;
+    for (VqProfRec& r : g_vq_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+            vqh_set_error("vqh_vq_profile_end: event query failed");
+            rc = VQH_ERR_LAUNCH;
+        } else if (out) {
+            out[0] += 1.0;
+            out[1] += (double)ms * 1e-3;
+            out[2] += r.flops;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_vq_prof.clear();
+    return rc;
+}
+
+// workspace (floats): hash table (3 T, T = power of two >= 2K) + K hashes (2K) + canon (K) + K code norms + R row norms +
+// R best scores + nsplit*R*(best, second, index) + R/4 flag bytes
 extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset,
                               int R, int K, int D, float rel_tol, float* workspace, long long workspace_floats,
                               hipStream_t stream) {
@@ -444,21 +631,30 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     VQH_CHECK_ARG(Z && E && idx_out && workspace, "vqh_vq_nearest: null pointer");
     VQH_CHECK_ARG(((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(E)) & 15) == 0 && (ldz & 3) == 0 && (lde & 3) == 0,
                   "vqh_vq_nearest: operands must be 16-byte aligned");
-    const int row_blocks = (R + 31) / 32;
-    int nsplit = 1;                              // fill ~2048 waves: split the code range when there are few rows
-    if (row_blocks < 1024) {
-        nsplit = (2048 + row_blocks - 1) / row_blocks;
+    // LDS-staged kernel: 128 rows per workgroup; D/8 in {1,2,4,8,16,32}
+    const int nt8 = D / 8;
+    const bool lds_form = !(g_vq_flags & 1) && D <= 256 && (nt8 & (nt8 - 1)) == 0;
+    const int rows_per_block = lds_form ? 128 : 32;
+    const int row_blocks = (R + rows_per_block - 1) / rows_per_block;
+    const int target = lds_form ? 512 : 2048;    // workgroups wanted (2 x 256 CUs / ~2048 single waves)
+    int nsplit = 1;                              // split the code range when there are few rows
+    if (row_blocks < target / 2) {
+        nsplit = (target + row_blocks - 1) / row_blocks;
         const int max_split = (K + 255) / 256;   // at least 256 codes per range
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
     }
-    int kchunk = ((K + nsplit - 1) / nsplit + 31) / 32 * 32;
+    int kchunk = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
     nsplit = (K + kchunk - 1) / kchunk;
-    const long long need = 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8;
+    int T = 64;
+    while (T < 2 * K) T <<= 1;
+    const long long need = 3LL * T + 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8;
     VQH_CHECK_ARG(need <= workspace_floats, "vqh_vq_nearest: workspace too small");
-    unsigned long long* hash = reinterpret_cast<unsigned long long*>(workspace);      // 2K floats, 8-byte aligned
-    int* canon = reinterpret_cast<int*>(workspace + 2 * (size_t)K);
-    float* enorm = workspace + 3 * (size_t)K;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);       // 2T floats, 8-byte aligned
+    int* minidx = reinterpret_cast<int*>(workspace + 2 * (size_t)T);
+    unsigned long long* hash = reinterpret_cast<unsigned long long*>(workspace + 3 * (size_t)T);   // 2K floats
+    int* canon = reinterpret_cast<int*>(workspace + 3 * (size_t)T + 2 * (size_t)K);
+    float* enorm = workspace + 3 * (size_t)T + 3 * (size_t)K;
     float* znorm = enorm + K;
     float* bestval = znorm + R;
     float* pbest = bestval + R;
@@ -468,9 +664,46 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, enorm, 1.f);
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, R, D, znorm, 1.f);
     hipLaunchKernelGGL(code_hash_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, hash);
-    hipLaunchKernelGGL(code_canon_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, hash, E, lde, K, D, canon);
-    hipLaunchKernelGGL(vq_nearest_kernel, dim3(row_blocks, nsplit), dim3(64), 0, stream, Z, ldz, E, lde, enorm, canon, pbest,
-                       psecond, pidx, R, K, D, kchunk);
+    hipLaunchKernelGGL(canon_init_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, keys, minidx, T);
+    hipLaunchKernelGGL(canon_insert_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, hash, K, keys, minidx, T);
+    hipLaunchKernelGGL(canon_lookup_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, hash, E, lde, K, D, keys, minidx, T, canon);
+    VqProfRec rec{};
+    if (g_vq_prof_on) {
+        rec.flops = 2.0 * R * (double)K * D;
+        if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess ||
+            hipEventRecord(rec.e0, stream) != hipSuccess) {
+            vqh_set_error("vqh_vq_nearest: profiling events failed");
+            return VQH_ERR_LAUNCH;
+        }
+    }
+    if (lds_form) {
+        const int ct = (nt8 >= 32) ? 32 : 64;
+        const size_t smem = (size_t)(2 * ct * (D + 4) + 4 * ct) * sizeof(float);
+#define VQ_LDS(N)                                                                                                        \
+    case N: {                                                                                                            \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_nearest_lds_kernel<N>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }                         \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL(vq_nearest_lds_kernel<N>, dim3(row_blocks, nsplit), dim3(256), smem, stream, Z, ldz, E, lde,  \
+                           enorm, canon, pbest, psecond, pidx, R, K, kchunk);                                            \
+    } break
+        switch (nt8) { VQ_LDS(1); VQ_LDS(2); VQ_LDS(4); VQ_LDS(8); VQ_LDS(16); VQ_LDS(32); default: break; }
+#undef VQ_LDS
+    } else {
+        hipLaunchKernelGGL(vq_nearest_kernel, dim3(row_blocks, nsplit), dim3(64), 0, stream, Z, ldz, E, lde, enorm, canon, pbest,
+                           psecond, pidx, R, K, D, kchunk);
+    }
+    if (g_vq_prof_on) {
+        if (hipEventRecord(rec.e1, stream) != hipSuccess) {
+            vqh_set_error("vqh_vq_nearest: profiling events failed");
+            return VQH_ERR_LAUNCH;
+        }
+        g_vq_prof.push_back(rec);
+    }
     hipLaunchKernelGGL(vq_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, pbest, psecond, pidx, canon, nsplit, znorm,
                        idx_out, idx_offset, amb, bestval, R, rel_tol);
     hipLaunchKernelGGL(vq_refine_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, E, lde, idx_out, idx_offset, amb,

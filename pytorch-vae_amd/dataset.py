@@ -77,3 +77,22 @@ class SyntheticCurveDataset(Dataset):
         xyz = xyz - xyz.mean(0, keepdim=True)
         ss = torch.nn.functional.one_hot(torch.randint(0, 3, (Lc,), generator=g), 3).float()
         return torch.cat([xyz, ss], -1)
+
+
+def synthetic_curve_batch(B: int, L: int, seed: int, ragged: bool = False, min_len: Optional[int] = None):
+    """One seeded synthetic batch in the layout pad_collate produces: xyz ~ 5*N(0,1) centred per sample
+    (dataset.py:121-122 of the reference centres every curve), random secondary-structure one-hot, zero padding; the first
+    sample always has the full length so that L_max == L.  Used by bench.py and the full-size tests (the reference's .npy
+    corpus is not available offline)."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = 5.0 * torch.randn(B, L, 3, generator=g)
+    ss = torch.nn.functional.one_hot(torch.randint(0, 3, (B, L), generator=g), 3).float()
+    mask = torch.ones(B, L, dtype=torch.bool)
+    if ragged:
+        lo = min_len if min_len is not None else max(3, L // 2)
+        lens = torch.randint(lo, L + 1, (B,), generator=g)
+        lens[0] = L
+        mask = torch.arange(L)[None, :] < lens[:, None]
+    m = mask.float()[..., None]
+    xyz = xyz - (xyz * m).sum(1, keepdim=True) / m.sum(1, keepdim=True)
+    return (torch.cat([xyz, ss], -1) * m).contiguous(), mask

@@ -56,7 +56,8 @@ _PROTOS = {
     "vqh_adamw_step": "pppplppp",
 }
 _CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "l": C.c_longlong, "u": C.c_uint}
-EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_set_flags", "vqh_attn_set_flags", "vqh_gemm_profile_begin", "vqh_gemm_profile_end"] + list(_PROTOS)
+EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_set_flags", "vqh_attn_set_flags", "vqh_gemm_profile_begin", "vqh_gemm_profile_end",
+           "vqh_vq_set_flags", "vqh_vq_profile_begin", "vqh_vq_profile_end"] + list(_PROTOS)
 
 
 def lib():
@@ -70,6 +71,7 @@ def lib():
         L.vqh_last_error.restype = C.c_char_p
         L.vqh_abi_version.restype = C.c_int
         L.vqh_gemm_profile_end.argtypes = [C.c_void_p]
+        L.vqh_vq_profile_end.argtypes = [C.c_void_p]
         for name, sig in _PROTOS.items():
             fn = getattr(L, name)
             fn.argtypes = [_CT[c] for c in sig]
@@ -131,6 +133,21 @@ def gemm_profile(fn):
                 if n > 0:
                     res[(fam, lay >> 1, lay & 1, mc - 1)] = (int(n), t, f)
     return res
+
+
+def vq_profile(fn):
+    """Run fn() with per-launch timing of the nearest-neighbour main kernel on; returns (launches, seconds, flops)."""
+    import ctypes
+    lib().vqh_vq_profile_begin()
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        out = (ctypes.c_double * 3)()
+        rc = lib().vqh_vq_profile_end(ctypes.cast(out, ctypes.c_void_p))
+    if rc != 0:
+        raise VqhError(f"vqh_vq_profile_end failed: {lib().vqh_last_error().decode()}")
+    return int(out[0]), out[1], out[2]
 
 
 def gemm_kernel_name(key):

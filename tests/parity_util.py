@@ -28,7 +28,8 @@ def scalar_tol(ref32, ref64=None, rel=REL, floor=FLOOR):
 
 
 def assert_scalar(got, ref32, ref64=None, what="", rel=REL):
-    got, ref32 = float(got), float(ref32)
+    got = float(got.detach()) if hasattr(got, "detach") else float(got)
+    ref32 = float(ref32)
     tol = scalar_tol(ref32, ref64, rel)
     assert abs(got - ref32) <= tol, f"{what}: got {got!r} vs reference {ref32!r} (|diff| {abs(got - ref32):.3e} > tol {tol:.3e})"
 

@@ -34,6 +34,7 @@ CASES = {
     "C2": (dict(G.C2_MODEL), 256, 64),                                                      # K=512 D=64, R=16384
     "C5_rank": (dict(G.C2_MODEL, codebook_size=8192, code_dim=256), 64, 256),               # K=8192 D=256, R=4096 (one rank of C5)
     "C4_quarter": (dict(G.C2_MODEL), 256, 256),                                             # L=256 (a quarter of C4's batch)
+    "C4": (dict(G.C2_MODEL), 1024, 256),                                                    # BASELINE config 4 at FULL size: 96 GiB of activations
     "stage2_rvq": (dict(G.C2_MODEL, num_quantizers=4, codebook_size=1024, code_dim=512), 32, 128),  # stage2_vq.yaml verbatim quantizer
 }
 
@@ -43,7 +44,7 @@ def test_full_size_properties(name):
     cfg, B, Lq = CASES[name]
     m, eng = _build(cfg)
     q = m.quantizer
-    x, mask = G.curve_batch(B, Lq, 77, ragged=(name == "C4_quarter"))
+    x, mask = G.curve_batch(B, Lq, 77, ragged=name.startswith("C4"))
     x, mask = x.to(DEV), mask.to(DEV)
     emb0, ecs0 = q.embedding.clone(), q.ema_cluster_size.clone()
     m.training_steps = 1
@@ -95,3 +96,42 @@ def test_c2_loss_decreases_on_a_fixed_batch():
         m.train_step(x, mask, W, 2e-4, 0.008, 3.0)
         losses.append(float(eng.metrics[0]))
     assert all(l == l for l in losses) and losses[-1] < 0.7 * losses[0], losses[::5]
+
+
+@pytest.mark.parametrize("R,K,D", [(65536, 512, 64), (262144, 8192, 256), (3000, 1000, 24), (777, 130, 8), (4096, 4096, 512)])
+def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
+    """SURVEY 8d's image-derived quantizer shapes (R = 256*16*16, K = 512, D = 64; R = 512*16*16*2, K = 8192, D = 256 -- the
+    reference materialises 2 x 134 MB .. 2 x 8.6 GB there) plus ragged / small / D = 512 shapes: the LDS-staged kernel and the
+    per-wave gather kernel return the same indices, and those equal an fp64 brute-force argmin (first minimum)."""
+    from vqvae_hip import lib as L
+    L.require_gpu()
+    torch.manual_seed(R + K + D)
+    z = torch.randn(R, D, device=DEV)
+    emb = torch.randn(K, D, device=DEV) / D ** 0.5
+    emb[K // 3] = emb[7]                                 # exact duplicate codes: the lower index must win
+    z[5] = emb[7]
+    ws = torch.empty(48 * 1024 * 1024, device=DEV)
+    got = []
+    for flags in (0, 1):
+        old = L.lib().vqh_vq_set_flags(flags)
+        try:
+            idx = torch.full((R,), -1, device=DEV, dtype=torch.int64)
+            L.call("vqh_vq_nearest", z, D, emb, D, idx, 0, R, K, D, 3e-5, ws, ws.numel())
+            torch.cuda.synchronize()
+        finally:
+            L.lib().vqh_vq_set_flags(old)
+        got.append(idx)
+    assert torch.equal(got[0], got[1])
+    want = torch.empty(R, dtype=torch.int64, device=DEV)
+    e64 = emb.double()
+    en = (e64 * e64).sum(1)[None]
+    for lo in range(0, R, 8192):                         # chunked fp64 brute force (R x K doubles would not fit at once)
+        zc = z[lo:lo + 8192].double()
+        want[lo:lo + 8192] = ((zc * zc).sum(1, keepdim=True) - 2.0 * zc @ e64.t() + en).argmin(1)
+    bad = torch.nonzero(got[0] != want).flatten()
+    if bad.numel():                                      # the expanded fp64 form itself rounds: settle those rows with the direct form
+        zc, cand = z[bad].double(), torch.stack([got[0][bad], want[bad]], 1)
+        dd = ((zc[:, None, :] - e64[cand]) ** 2).sum(-1)
+        ok = (dd[:, 0] < dd[:, 1]) | ((dd[:, 0] == dd[:, 1]) & (cand[:, 0] <= cand[:, 1]))
+        assert bool(ok.all()), f"{int((~ok).sum())} rows are not the exact nearest code"
+    assert int(got[0][5]) == 7
