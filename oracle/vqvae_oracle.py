@@ -338,6 +338,11 @@ class OracleVQVAE:
         K, D = self.K, rows.shape[1]
         cnt = torch.zeros(K, dtype=rows.dtype).index_add_(0, idx, torch.ones(idx.shape[0], dtype=rows.dtype))
         ssum = torch.zeros(K, D, dtype=rows.dtype).index_add_(0, idx, rows)
+        hook = getattr(self, "stats_hook", None)
+        if hook is not None:
+            # N-rank semantics of the build (NOT in the reference): the per-level statistics are summed over
+            # the ranks before the refresh; the data-parallel tests install an all-reduce here
+            cnt, ssum = hook(cnt, ssum)
         ecs, eemb, emb = (self.sd["quantizer.ema_cluster_size"], self.sd["quantizer.ema_embedding"],
                           self.sd["quantizer.embedding"])
         ecs.mul_(self.decay).add_(cnt * (1 - self.decay))

@@ -131,6 +131,7 @@ class VQVAEExperiment:
         self.lr_policy: Optional[LRPolicy] = None
         self.logged: Dict[str, float] = {}
         self._ep_n = 0
+        self._val_sum, self._val_n = None, 0
 
     # ---- data (reference :122-153) -------------------------------------------------------------------
     def setup(self, stage: Optional[str] = None):
@@ -278,6 +279,10 @@ class VQVAEExperiment:
         if self.lr_policy is not None:
             self.lr_policy.on_step()
         n = int(self.exp_params.get("print_every", 0))
+        if n > 0 and batch_idx % n == 0:
+            # the reference logs ~20 scalars per step with sync_dist=True (experiment.py:402-437: ~10 scalar all-reduces
+            # every step); here the whole metric vector is averaged over the ranks in ONE all-reduce per logging interval
+            metrics = self._rank_mean(metrics)
         if n > 0 and batch_idx % n == 0 and self.global_rank == 0:
             names = self.model.metric_names()
             md = dict(zip(names, [float(v) for v in metrics.tolist()]))       # the only host sync, every n steps
@@ -288,16 +293,41 @@ class VQVAEExperiment:
                   f"ss_loss={md['Reconstruction_Loss_SS']:.3f} | lr={lr:.6f}", flush=True)
         return metrics
 
+    def _rank_mean(self, vec):
+        """Mean of a metric vector over the data-parallel ranks (one batched all-reduce; identity for one process)."""
+        d = torch.distributed
+        if d.is_available() and d.is_initialized() and d.get_world_size() > 1 and torch.is_tensor(vec):
+            vec = vec.clone()
+            d.all_reduce(vec)
+            vec = vec / d.get_world_size()
+        return vec
+
     def validation_step(self, batch, batch_idx):
         x, mask = batch
-        return self.model.eval_step(x, mask, self.loss_weights())
+        metrics = self.model.eval_step(x, mask, self.loss_weights())
+        # running sums on the device (no host sync per batch); averaged, rank-reduced and logged at epoch end
+        if torch.is_tensor(metrics):
+            self._val_sum = metrics.clone() if self._val_sum is None else self._val_sum + metrics
+        self._val_n += 1
+        return metrics
 
     def on_validation_epoch_start(self):
+        self._val_sum, self._val_n = None, 0
         q = getattr(self.model, "quantizer", None)
         if q is not None and hasattr(q, "reset_epoch_stats"):
             q.reset_epoch_stats()
 
     def on_validation_epoch_end(self):
+        if self._val_n > 0 and self._val_sum is not None:
+            mean = self._rank_mean(self._val_sum / float(self._val_n))          # val/* metrics (experiment.py:478-479, :402-437)
+            names = self.model.metric_names()
+            md = dict(zip(names, [float(v) for v in mean.tolist()]))
+            self.logged.update({f"val/{k}": v for k, v in md.items()})
+            if self.trainer is not None:
+                self.trainer.callback_metrics.update({f"val/{k}": v for k, v in md.items()})
+            if self.global_rank == 0:
+                print(f"[Val {int(self.current_epoch)}] loss={md['loss']:.4f} xyz={md['Reconstruction_Loss_XYZ']:.4f} "
+                      f"ss_loss={md['Reconstruction_Loss_SS']:.4f} vq={md['VQ_Loss']:.4f}")
         q = getattr(self.model, "quantizer", None)
         if q is not None and hasattr(q, "get_epoch_stats"):
             st = q.get_epoch_stats()
@@ -305,9 +335,10 @@ class VQVAEExperiment:
                 print(f"[Val Stats] PPL: {st.get('perplexity', 0):.2f}, Dead Ratio: {st.get('dead_ratio', 0):.3f}")
 
     def on_train_epoch_end(self):
-        if self._ep_n > 0 and self.global_rank == 0 and hasattr(self.model, "metric_sums"):
+        sums = self._rank_mean(self.model.metric_sums()) if (self._ep_n > 0 and hasattr(self.model, "metric_sums")) else None
+        if sums is not None and self.global_rank == 0:
             names = self.model.metric_names()
-            md = dict(zip(names, [float(v) / self._ep_n for v in self.model.metric_sums().tolist()]))
+            md = dict(zip(names, [float(v) / self._ep_n for v in sums.tolist()]))
             lr = self.lr_policy.current()[0] if self.lr_policy is not None else self.LR
             print(f"[Epoch {int(self.current_epoch)}] loss={md['loss']:.4f} xyz={md['Reconstruction_Loss_XYZ']:.4f} "
                   f"ss_loss={md['Reconstruction_Loss_SS']:.4f} rmsd_aln={md['RMSD_Aligned']:.4f}A "

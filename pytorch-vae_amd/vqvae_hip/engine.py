@@ -31,15 +31,38 @@ LN_EPS = 1e-5
 VQ_EPS = 1e-5
 WS_FLOATS = 48 * 1024 * 1024
 
-# backward phases in completion order and the parameter-name prefixes each one finishes (see StepEngine._flatten)
-BWD_PHASES = (("from_code.", "mem_ln.", "decoder.", "query_embed.", "head_xyz.", "head_ss."),
-              ("tokenizer.", "to_code."),
-              ("fuse_mlp.", "ln_ss.", "ss_encoder.", "ss_input_proj."),
-              ("ln_geo.", "enc_ln.", "encoder.", "input_proj."))
+def bwd_phases(num_layers):
+    """Backward phases in completion order: the parameter-name prefixes whose gradients are final when the phase ends
+    (see StepEngine._flatten / backward_gen).  One phase per decoder layer, the tokenizer, the SS encoder + fusion MLP, and
+    one per geometry-encoder layer: each phase's gradients are one contiguous all-reduce bucket that travels while the
+    next phase computes, and the only exposed bucket is the last one -- geometry layer 0 + input_proj, 7 % of the bytes
+    at C2 (round 1 used 4 coarse phases and left 29 % exposed)."""
+    nl = int(num_layers)
+    dec = []
+    for i in reversed(range(nl)):
+        pre = (f"decoder.layers.{i}.",)
+        if i == nl - 1:
+            pre += ("head_xyz.", "head_ss.")
+        if i == 0:
+            pre += ("query_embed.", "mem_ln.", "from_code.")
+        dec.append(pre)
+    if not dec:
+        dec = [("head_xyz.", "head_ss.", "query_embed.", "mem_ln.", "from_code.")]
+    geo = []
+    for i in reversed(range(nl)):
+        pre = (f"encoder.layers.{i}.",)
+        if i == nl - 1:
+            pre += ("ln_geo.", "enc_ln.")
+        if i == 0:
+            pre += ("input_proj.",)
+        geo.append(pre)
+    if not geo:
+        geo = [("ln_geo.", "enc_ln.", "input_proj.")]
+    return tuple(dec) + (("tokenizer.", "to_code."), ("fuse_mlp.", "ln_ss.", "ss_encoder.", "ss_input_proj.")) + tuple(geo)
 
 
-def _bwd_phase(name):
-    for i, prefixes in enumerate(BWD_PHASES):
+def _bwd_phase(name, phases):
+    for i, prefixes in enumerate(phases):
         if name.startswith(prefixes):
             return i
     raise KeyError(f"parameter {name!r} is not assigned to a backward phase")
@@ -132,12 +155,13 @@ class StepEngine:
         named = list(self.m.named_parameters())
         # Layout = the order in which backward completes the gradients, so that each phase's gradients are one
         # contiguous bucket whose all-reduce can start while the next phase still computes:
-        #   decode_bwd | tokenize_bwd | encode_bwd (SS branch + fuse) | encode_bwd (geometry branch) | EMA statistics
+        #   decoder layers n-1..0 | tokenizer | SS encoder + fuse | geometry layers n-1..0 | EMA statistics   (bwd_phases)
+        self.phases = bwd_phases(self.m.num_layers)
         offs, total, bounds = {}, 0, []
-        for ph in range(len(BWD_PHASES)):
+        for ph in range(len(self.phases)):
             lo = total
             for n, p in named:
-                if _bwd_phase(n) == ph:
+                if _bwd_phase(n, self.phases) == ph:
                     offs[n] = total
                     total += (p.numel() + 3) // 4 * 4
             bounds.append((lo, total))
@@ -444,7 +468,8 @@ class StepEngine:
 
     def encode_bwd(self, d_hf):
         self.encode_bwd_ss(d_hf)
-        self.encode_bwd_geo()
+        for _ in self.encode_bwd_geo():
+            pass
 
     def encode_bwd_ss(self, d_hf):
         """fuse_mlp and the secondary-structure encoder; leaves d(cat) for encode_bwd_geo."""
@@ -464,7 +489,8 @@ class StepEngine:
         xs = c["ss_xs"]
         dres = self.T("tmp.dres_seq", ML, H)
         self.ln_bwd("ln_ss", dcat[:, H:], 2 * H, xs[-1], H, "ln_ss", dres, H, False, ML)
-        self._encoder_stack_bwd("ss_encoder", SS_LAYERS, xs, dres, ML, B, Lq, mask)
+        for _ in self._encoder_stack_bwd("ss_encoder", SS_LAYERS, xs, dres, ML, B, Lq, mask):
+            pass
         call("vqh_embed_bwd", dres, c["x"], 6, 3, self.G["ss_input_proj.weight"], self.G["ss_input_proj.bias"], 0.0, ML, H,
              self.rng, 0, 0.0, self.ws, self.ws.numel())
 
@@ -481,8 +507,10 @@ class StepEngine:
             if i > 0:
                 nxt = (self.site(f"{stack}.layers.{i - 1}.linear2.drop"), self.pdrop(0.1), "tmp.dy")
             dy = self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask, dy_in=dy, emit=nxt)
+            yield i                                   # layer i's gradients are final
 
     def encode_bwd_geo(self):
+        """Generator: yields after every geometry-encoder layer (its gradients are final = one all-reduce bucket)."""
         c = self.ctx
         B, Lq, H = c["B"], c["L"], self.H
         ML, mask = B * Lq, c["mask"]
@@ -491,9 +519,17 @@ class StepEngine:
         dhg = self.T("tmp.dh", ML, H)
         self.ln_bwd("ln_geo", dcat, 2 * H, self.buf["enc_ln.y"], H, "ln_geo", dhg, H, False, ML)
         self.ln_bwd("enc_ln", dhg, H, xs[-1], H, "enc_ln", dres, H, False, ML)
-        self._encoder_stack_bwd("encoder", self.m.num_layers, xs, dres, ML, B, Lq, mask)
-        call("vqh_embed_bwd", dres, c["x"], 6, 0, self.G["input_proj.weight"], self.G["input_proj.bias"], 0.0, ML, H,
-             self.rng, self.site("inp_dropout"), self.pdrop(0.1), self.ws, self.ws.numel())
+        embed_done = False
+        for i in self._encoder_stack_bwd("encoder", self.m.num_layers, xs, dres, ML, B, Lq, mask):
+            if i == 0:                                # input_proj belongs to the last phase
+                call("vqh_embed_bwd", dres, c["x"], 6, 0, self.G["input_proj.weight"], self.G["input_proj.bias"], 0.0, ML, H,
+                     self.rng, self.site("inp_dropout"), self.pdrop(0.1), self.ws, self.ws.numel())
+                embed_done = True
+            yield i
+        if not embed_done:                            # num_layers == 0
+            call("vqh_embed_bwd", dres, c["x"], 6, 0, self.G["input_proj.weight"], self.G["input_proj.bias"], 0.0, ML, H,
+                 self.rng, self.site("inp_dropout"), self.pdrop(0.1), self.ws, self.ws.numel())
+            yield 0
 
     def tokenize(self, hf, mask, B, Lq):
         """LatentTokenizer + to_code (models/vq_vae.py:310-322, 736-743) -> z_e [B*N, D]"""
@@ -584,7 +620,21 @@ class StepEngine:
         return p
 
     def quantize(self, z_e, B, do_ema_update, row_valid=None):
-        """VectorQuantizerEMA.forward (models/vq_vae.py:170-283). z_e [B*N, D] -> z_st, z_q, idx, stats
+        """quantize_gen driven to completion, with the per-level statistics all-reduce done inline (eager callers)."""
+        gen = self.quantize_gen(z_e, B, do_ema_update, row_valid)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+            torch.distributed.all_reduce(self.flat_gx[self.n_flat:])      # RCCL sum of the EMA statistics over ranks
+
+    def quantize_gen(self, z_e, B, do_ema_update, row_valid=None):
+        """Generator form: yields where the EMA statistics [cnt | sum] of a level must be summed over the ranks BEFORE that
+        level's table refresh (world > 1 and not deferred: residual VQ :251-258, or the usage-entropy regulariser) -- the
+        caller all-reduces self.flat_gx[self.n_flat:], between two graph segments when the step is captured.
+
+        VectorQuantizerEMA.forward (models/vq_vae.py:170-283). z_e [B*N, D] -> z_st, z_q, idx, stats
         row_valid [B*N] bool (the optional `mask` of :175): only valid positions feed the EMA statistics (:192-197,
         :251-256) and, single level only, the usage histogram (:202-205); VQVAE.forward never passes one (:869)."""
         q = self.m.quantizer
@@ -603,8 +653,8 @@ class StepEngine:
             row_valid = row_valid.reshape(-1).contiguous()
             if not bool(row_valid.any()):          # no valid position: the reference skips the update (:196, :253)
                 upd = False
-        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
-            torch.distributed.get_world_size() > 1
+        from .parallel import dp_active
+        multi = dp_active()
         rows = z_e
         res = [self.T("vq.res0", R, D), self.T("vq.res1", R, D)]
         for lv in range(Q):
@@ -636,7 +686,7 @@ class StepEngine:
                 self._pending_ema = float(q.decay)
             elif upd:
                 if multi:                                   # RCCL sum of the EMA statistics over ranks
-                    torch.distributed.all_reduce(self.flat_gx[self.n_flat:])
+                    yield "stats"
                 self.apply_ema(float(q.decay))
             rows = nxt
         z_q, z_st = self.T("vq.z_q", R, D), self.T("vq.z_st", R, D)
@@ -735,7 +785,12 @@ class StepEngine:
         return rec
 
     def decode_bwd(self, d_rec, d_z, z_beta):
-        """d_rec [B*L, 6] -> d_z [B*N, D] written as z_beta*d_z + grad (straight-through adds onto the commitment grad)."""
+        for _ in self.decode_bwd_gen(d_rec, d_z, z_beta):
+            pass
+
+    def decode_bwd_gen(self, d_rec, d_z, z_beta):
+        """d_rec [B*L, 6] -> d_z [B*N, D] written as z_beta*d_z + grad (straight-through adds onto the commitment grad).
+        Generator: yields after every decoder layer (phase boundary); the last yield follows the memory / query tail."""
         c = self.ctx
         B, Lq, Nmem, H, D = c["dec_B"], c["dec_L"], c["dec_N"], self.H, self.D
         ML, MN, mask = B * Lq, B * c["dec_N"], c["dec_mask"]
@@ -765,6 +820,8 @@ class StepEngine:
                 dx_sh, dy = out, None
             else:
                 dy = out
+            if i > 0:
+                yield i
         # tgt = query_embed[:L] + pos_enc[:L] broadcast over the batch
         gq = self.G["query_embed.weight"]
         call("vqh_memset", gq, 0, gq.numel() * 4)
@@ -775,6 +832,7 @@ class StepEngine:
         self.ln_bwd("mem_ln", d_mem, H, self.buf["dec.memf"], H, "mem_ln", dmemf, H, False, MN)
         self.lin_wgrad(dmemf, H, c["dec_z"], D, MN, self.G["from_code.weight"], self.G["from_code.bias"])
         self.lin_dgrad(dmemf, H, MN, self.P["from_code.weight"], d_z, D, beta=z_beta)
+        yield 0
 
     # ------------------------------------------------------------------ whole step
     def forward(self, x, mask, train=True):
@@ -831,6 +889,15 @@ class StepEngine:
         return bool(self.train and m.use_vq and (m.training_steps >= m.ema_update_freeze_steps))
 
     def _forward_core(self, x, mask, upd):
+        gen = self._forward_core_gen(x, mask, upd)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+            torch.distributed.all_reduce(self.flat_gx[self.n_flat:])
+
+    def _forward_core_gen(self, x, mask, upd):
         m = self.m
         self.ctx = {}
         self.fwd_id += 1
@@ -841,7 +908,7 @@ class StepEngine:
         if not m.use_vq:
             z_dec, z_q, idx, stats = z_e, z_e, None, None
         else:
-            z_dec, z_q, idx, stats = self.quantize(z_e, B, upd)
+            z_dec, z_q, idx, stats = yield from self.quantize_gen(z_e, B, upd)
         rec = self.decode(z_dec, mask, B, Lq)
         c["z_e"], c["z_q"], c["idx"], c["rec"], c["stats"] = z_e, z_q, idx, rec, stats
         return rec, z_e, z_q, idx, stats
@@ -897,20 +964,21 @@ class StepEngine:
 
     def backward(self):
         """Fill the flat gradient buffer from the d_rec / d_ze left by loss()."""
-        for ph in range(len(BWD_PHASES)):
-            self.backward_phase(ph)
+        for _ in self.backward_gen():
+            pass
 
-    def backward_phase(self, ph):
-        """Phase ph of backward; when it returns, bucket self.buckets[ph] of the flat gradient is final."""
+    def backward_gen(self):
+        """Backward as a generator over the phases of bwd_phases(): after the k-th yield, bucket self.buckets[k] of the flat
+        gradient is final (its all-reduce may start)."""
         c = self.ctx
-        if ph == 0:
-            self.decode_bwd(c["d_rec"], c["d_ze"], 1.0 if self.m.use_vq else 0.0)
-        elif ph == 1:
-            c["d_hf"] = self.tokenize_bwd(c["d_ze"])
-        elif ph == 2:
-            self.encode_bwd_ss(c["d_hf"])
-        else:
-            self.encode_bwd_geo()
+        for _ in self.decode_bwd_gen(c["d_rec"], c["d_ze"], 1.0 if self.m.use_vq else 0.0):
+            yield
+        c["d_hf"] = self.tokenize_bwd(c["d_ze"])
+        yield
+        self.encode_bwd_ss(c["d_hf"])
+        yield
+        for _ in self.encode_bwd_geo():
+            yield
 
     def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         """Host -> device scalars of the next optimizer step (copied on the current stream, outside any graph)."""
@@ -947,25 +1015,47 @@ class StepEngine:
             works.append(w)
 
     # ------------------------------------------------------------------ fused training step
-    def _step_forward(self, x_in, x_tgt, mask, weights, upd):
+    def _step_gen(self, x_in, x_tgt, mask, weights, upd):
+        """The whole training step as a generator.  Every yield is a point where a collective has to run when world > 1:
+            ("stats",)      sum the EMA statistics of one quantizer level before its table refresh (residual VQ /
+                            usage-entropy regulariser only; a single level defers its refresh behind the last bucket)
+            ("bucket", k)   gradients of backward phase k are final: start the all-reduce of bucket k
+            ("wait",)       all buckets must have arrived: the optimizer follows
+        A single process ignores the yields (one graph holds everything); with several ranks the stretches between two
+        yields become separate hipGraph segments and the collectives run between their replays (StepEngine._replay)."""
         self.advance_rng()
-        rec, z_e, z_q, idx, stats = self._forward_core(x_in, mask, upd)
+        fwd = self._forward_core_gen(x_in, mask, upd)
+        while True:
+            try:
+                next(fwd)
+            except StopIteration as stop:
+                rec, z_e, z_q, idx, stats = stop.value
+                break
+            yield ("stats",)
         self.loss(rec, x_tgt, mask, z_e, z_q, stats, weights)
-
-    def _step_part_a(self, x_in, x_tgt, mask, weights, upd):
-        self._step_forward(x_in, x_tgt, mask, weights, upd)
-        self.backward()
-
-    def _step_eager_dp(self, x_in, x_tgt, mask, weights, upd):
-        """world_size > 1 without graphs: backward phase by phase, each bucket's all-reduce overlapping the next phase."""
-        self._step_forward(x_in, x_tgt, mask, weights, upd)
-        works = []
-        for ph in range(len(BWD_PHASES)):
-            self.backward_phase(ph)
-            self.allreduce_bucket(ph, works)
-        for w in works:
-            w.wait()
+        ph = 0
+        for _ in self.backward_gen():
+            yield ("bucket", ph)
+            ph += 1
+        yield ("wait",)
         self._step_part_b()
+
+    def _act(self, action, works):
+        """Run one collective point of _step_gen (world > 1)."""
+        if action[0] == "stats":
+            torch.distributed.all_reduce(self.flat_gx[self.n_flat:])
+        elif action[0] == "bucket":
+            self.allreduce_bucket(action[1], works)
+        elif action[0] == "wait":
+            for w in works:
+                w.wait()
+            del works[:]
+
+    def _step_eager(self, x_in, x_tgt, mask, weights, upd, dp):
+        works = []
+        for action in self._step_gen(x_in, x_tgt, mask, weights, upd):
+            if dp:
+                self._act(action, works)
 
     def _step_part_b(self):
         self.finish_ema()
@@ -978,28 +1068,20 @@ class StepEngine:
             self.maybe_reinit_dead_codes()
         return out
 
-    def _capturable(self, dp):
-        """Can this configuration's step live in hipGraphs?  A collective issued from INSIDE the forward cannot be
-        captured: with world_size > 1 that is residual VQ (per-level statistics reduce, models/vq_vae.py:251-258) and the
-        single-level usage-entropy regulariser (it reads the refreshed table, so the statistics are reduced in the forward).
-        Those run eager, phase by phase; everything else is captured."""
-        m = self.m
-        return not (dp and m.use_vq and (m.num_quantizers > 1 or not self.defer_ema))
-
-    def _replay(self, g, dp, upd, decay):
+    def _replay(self, segs, dp, upd, decay):
+        """segs = [(graph, action after it)]: one graph for a single process, one per stretch between collectives else."""
         if not dp:
-            g[0].replay()
+            segs[0][0].replay()
             return
-        # graph segments = forward+loss+phase 0, phases 1..3, optimizer; one async all-reduce after each phase
-        self._pending_ema = decay if (upd and self.m.num_quantizers == 1) else None
+        # host-side state the captured forward set while being recorded: a deferred single-level EMA refresh rides
+        # behind the last gradient bucket (allreduce_bucket appends the statistics when _pending_ema is set)
+        self._pending_ema = decay if (upd and self.m.use_vq and self.m.num_quantizers == 1 and self.defer_ema) else None
         works = []
-        for ph in range(len(BWD_PHASES)):
-            g[ph].replay()
-            self.allreduce_bucket(ph, works)
-        for w in works:
-            w.wait()
+        for g, action in segs:
+            g.replay()
+            if action is not None:
+                self._act(action, works)
         self._pending_ema = None
-        g[-1].replay()
 
     def _train_step(self, x, mask, weights, lr, weight_decay, clip, use_graph=True):
         """One whole training step (experiment.py:453 training_step + Lightning backward/clip/AdamW) on the GPU.
@@ -1030,59 +1112,57 @@ class StepEngine:
             ms = self.T("in.mask", *mask.shape, dtype=torch.bool)
             ms.copy_(mask, non_blocking=True)
         use_graph = bool(use_graph) and os.environ.get("VQH_GRAPH", "1") != "0"
-        g = a.graphs.get(key) if use_graph else None
-        if g is not None:
+        segs = a.graphs.get(key) if use_graph else None
+        if segs is not None:
             a.graphs.move_to_end(key)
             self.last_step_mode = "graph"
-            self._replay(g, dp, upd, decay)
+            self._replay(segs, dp, upd, decay)
             return self.metrics
         if len(a.seen) > 64:                       # scheduled weights change every epoch: forget keys without a graph
             a.seen = {k: v for k, v in a.seen.items() if k in a.graphs}
         seen = a.seen.get(key, 0)
         a.seen[key] = seen + 1
         # the first step at a (shape, key) runs eager and allocates the arena; the second one captures
-        if not (use_graph and seen >= 1 and self._capturable(dp)):
+        if not (use_graph and seen >= 1):
             self.last_step_mode = "eager"
-            if dp:
-                self._step_eager_dp(xs, xt, ms, weights, upd)
-            else:
-                self._step_part_a(xs, xt, ms, weights, upd)
-                self._step_part_b()
+            self._step_eager(xs, xt, ms, weights, upd, dp)
             return self.metrics
         self.last_step_mode = "capture"
         torch.cuda.synchronize()
-        graphs = []
+        segs = []
         try:
             # thread_local: the RCCL watchdog thread may query events while this thread captures
+            gen = self._step_gen(xs, xt, ms, weights, upd)
             if not dp:
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    self._step_part_a(xs, xt, ms, weights, upd)
-                    self._step_part_b()
-                graphs = [ga]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for _ in gen:
+                        pass
+                segs.append((g, None))
             else:
-                for ph in range(len(BWD_PHASES)):
-                    gp = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gp, capture_error_mode="thread_local"):
-                        if ph == 0:
-                            self._step_forward(xs, xt, ms, weights, upd)
-                        self.backward_phase(ph)
-                    graphs.append(gp)
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                    self._step_part_b()
-                graphs.append(gb)
+                # Record the step segment by segment.  Nothing executes during capture, so the collectives between the
+                # segments are skipped here; the replay below runs the step for real, collectives included.
+                done = False
+                while not done:
+                    g = torch.cuda.CUDAGraph()
+                    action = None
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        try:
+                            action = next(gen)
+                        except StopIteration:
+                            done = True
+                    segs.append((g, action))
         except BaseException:
-            # No silent eager fallback: a failure inside capture is a bug in the step (or a configuration _capturable()
-            # should have excluded) and would otherwise hide behind slower launches.  VQH_GRAPH=0 runs without graphs.
+            # No silent eager fallback: a failure inside capture is a bug in the step and would otherwise hide behind
+            # slower launches.  VQH_GRAPH=0 runs without graphs.
             self._pending_ema = None
             a.seen.pop(key, None)
             raise
         self._pending_ema = None
-        a.graphs[key] = tuple(graphs)
+        a.graphs[key] = segs
         while len(a.graphs) > MAX_GRAPHS_PER_ARENA:
             a.graphs.popitem(last=False)
-        self._replay(a.graphs[key], dp, upd, decay)
+        self._replay(segs, dp, upd, decay)
         return self.metrics
 
     def eval_step(self, x, mask, weights):

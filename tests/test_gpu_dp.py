@@ -17,7 +17,7 @@ B, LQ, SEED, STEPS = 8, 24, 515, 3
 W = dict(G.BASE_LOSS_WEIGHTS, xyz_tv_lambda=0.001)
 
 
-def _run(x, mask, use_graph=True):
+def _run(x, mask, use_graph=True, CFG=CFG):
     from models import vae_models
     m = vae_models["VQVAE"](**CFG)
     m.load_state_dict(G.model_state(CFG, SEED), strict=True)
@@ -31,7 +31,8 @@ def _run(x, mask, use_graph=True):
     return ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, eng.metrics.cpu().clone())
 
 
-def _worker(r, world, port, q):
+def _worker(r, world, port, q, cfg_name="vq"):
+    CFG = dict(G.SMALL_VQ) if cfg_name == "vq" else dict(G.SMALL_RVQ) if cfg_name == "rvq" else dict(G.SMALL_VQ, usage_entropy_lambda=0.05)
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.join(here, "..", "pytorch-vae_amd"), os.path.join(here, "golden"), here):
         sys.path.insert(0, p)
@@ -40,18 +41,23 @@ def _worker(r, world, port, q):
     from vqvae_hip.parallel import shard_bounds
     x, mask = G.curve_batch(B, LQ, SEED + 1, ragged=False)
     lo, hi = shard_bounds(B)
-    sd, met = _run(x[lo:hi].cuda(), mask[lo:hi].cuda())
+    sd, met = _run(x[lo:hi].cuda(), mask[lo:hi].cuda(), CFG=CFG)
     if r == 0:
         q.put({k: v.numpy() for k, v in sd.items()})      # by value: the producer may exit before the parent reads
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_train_steps_equal_single_process():
-    port = 29600 + (os.getpid() % 2000)
+@pytest.mark.parametrize("cfg_name", ["vq", "rvq", "uent"])
+def test_two_rank_train_steps_equal_single_process(cfg_name):
+    """vq: one level, EMA statistics deferred behind the last gradient bucket.  rvq / uent: the statistics are reduced
+    inside the forward (per level / before the regulariser reads the refreshed table): the captured step is split into
+    graph segments around those collectives as well (round 1 ran these configurations without graphs)."""
+    CFG = dict(G.SMALL_VQ) if cfg_name == "vq" else dict(G.SMALL_RVQ) if cfg_name == "rvq" else dict(G.SMALL_VQ, usage_entropy_lambda=0.05)
+    port = 29600 + (os.getpid() % 2000) + {"vq": 0, "rvq": 1, "uent": 2}[cfg_name]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, cfg_name)) for r in range(2)]
     for p in procs:
         p.start()
     sd2 = {k: torch.from_numpy(v) for k, v in q.get(timeout=600).items()}
@@ -59,8 +65,8 @@ def test_two_rank_train_steps_equal_single_process():
         p.join(timeout=600)
         assert p.exitcode == 0
     x, mask = G.curve_batch(B, LQ, SEED + 1, ragged=False)
-    sd1, _ = _run(x.cuda(), mask.cuda())
-    sd1e, _ = _run(x.cuda(), mask.cuda(), use_graph=False)
+    sd1, _ = _run(x.cuda(), mask.cuda(), CFG=CFG)
+    sd1e, _ = _run(x.cuda(), mask.cuda(), use_graph=False, CFG=CFG)
     for k in sd1:
         if k.startswith("quantizer._ep_"):      # epoch usage diagnostics are per-rank (local shard) by design
             continue

@@ -201,6 +201,9 @@ def test_alternating_shapes_graph_equals_eager_and_follows_oracle(cfg_name):
     for i, met in enumerate(metg):
         md = dict(zip(METRIC_KEYS, met.tolist()))
         for k, v in l32[i].items():
+            if k == "SS_Accuracy":        # a count of argmax hits: one near-tied logit pair moves it by 1 / #positions
+                assert abs(md[k] - v) <= 0.03, (i, md[k], v)
+                continue
             # VQ_Loss = beta * |z_e - sum of levels|^2 is the energy of the LAST residual: a difference of nearly equal
             # vectors, so a 1e-4 drift of z_e shows up ~10x larger there (residual VQ only)
             assert_scalar(md[k], v, l64[i][k], f"step {i} {k}", rel=1e-2 if k == "VQ_Loss" else 2e-3)

@@ -284,15 +284,26 @@ def test_warm_start_filter_drops_quantizer_and_shape_mismatches():
 
 
 def test_backward_phase_buckets_cover_every_parameter():
-    """The flat gradient buffer is laid out by backward phase (engine.BWD_PHASES) so that each phase's gradients form
-    one contiguous all-reduce bucket: every parameter of both shipped configurations must belong to exactly one phase."""
-    from vqvae_hip.engine import BWD_PHASES, _bwd_phase
+    """The flat gradient buffer is laid out by backward phase (engine.bwd_phases: one per decoder layer, tokenizer, SS
+    encoder + fusion, one per geometry-encoder layer) so that each phase's gradients form one contiguous all-reduce
+    bucket: every parameter of the shipped configurations must belong to exactly one phase, and the bucket that is
+    exposed before the optimizer (the last one) must stay below 10 % of the gradient bytes at the true model width."""
+    from vqvae_hip.engine import bwd_phases, _bwd_phase
     import gen_inputs as G
     from gen_inputs import O
     for cfg_kw in (G.C2_MODEL, G.SMALL_RVQ, G.SMALL_AE):
-        names = list(O.param_shapes(O.make_cfg(**cfg_kw)))
-        phases = [_bwd_phase(n) for n in names]
-        assert set(phases) == set(range(len(BWD_PHASES)))
+        cfg = O.make_cfg(**cfg_kw)
+        shapes = O.param_shapes(cfg)
+        names = list(shapes)
+        PH = bwd_phases(cfg["num_layers"])
+        assert len(PH) == 2 * cfg["num_layers"] + 2
+        phases = [_bwd_phase(n, PH) for n in names]
+        assert set(phases) == set(range(len(PH)))
         for n, ph in zip(names, phases):
-            assert sum(n.startswith(p) for p in BWD_PHASES[ph]) == 1
-            assert all(not n.startswith(p) for j, pr in enumerate(BWD_PHASES) if j != ph for p in pr), n
+            assert sum(n.startswith(p) for p in PH[ph]) == 1
+            assert all(not n.startswith(p) for j, pr in enumerate(PH) if j != ph for p in pr), n
+        if cfg_kw is G.C2_MODEL:
+            size = [0] * len(PH)
+            for n, ph in zip(names, phases):
+                size[ph] += int(np.prod(shapes[n]))
+            assert size[-1] / sum(size) < 0.10, size
