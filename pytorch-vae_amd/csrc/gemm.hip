@@ -887,7 +887,8 @@ static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const fl
         }
         int kchunk_d = ((K + splits_d - 1) / splits_d + dma::TBK - 1) / dma::TBK * dma::TBK;
         splits_d = (K + kchunk_d - 1) / kchunk_d;
-        if (tiles_d * splits_d >= 96) {                 // enough workgroups to be worth a 256-row tile
+        const bool pairs_fit = (long long)M * N / 2 < (1LL << 32);     // the kernel's 32-bit dropout pair index
+        if (tiles_d * splits_d >= 96 && pairs_fit) {                 // enough workgroups to be worth a 256-row tile
             g.kchunk = kchunk_d;
             if (splits_d > 1) {
                 g.ws = workspace;
