@@ -37,6 +37,58 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// 16-byte form: the row lives in registers (NV quads per lane), one read and one write of x/y per element -- the scalar
+// kernel above walks the row three times with 4-byte accesses and reached 3.4 TB/s (43 % of HBM) at H = 512.
+// Two-pass statistics (mean, then centred squares) on the registers: same formula as the scalar kernel.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                float* __restrict__ y, int ldy, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int rows, int H, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = H >> 2;
+    f32x4 wv[NV], bv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int q = lane + 64 * j;
+        wv[j] = (q < nq) ? *reinterpret_cast<const f32x4*>(w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[j] = (q < nq) ? *reinterpret_cast<const f32x4*>(b + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float invH = 1.f / (float)H;
+    for (int row = blockIdx.x * WAVES_PER_BLOCK + wave; row < rows; row += gridDim.x * WAVES_PER_BLOCK) {
+        const float* xr = x + (size_t)row * ldx;
+        f32x4 xv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = lane + 64 * j;
+            xv[j] = (q < nq) ? *reinterpret_cast<const f32x4*>(xr + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+        }
+        const float mu = wave_sum(s) * invH;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = lane + 64 * j;
+            if (q < nq) {
+                const f32x4 d = xv[j] - mu;
+                v += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        }
+        const float rs = rsqrtf(wave_sum(v) * invH + eps);
+        float* yr = y + (size_t)row * ldy;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = lane + 64 * j;
+            if (q < nq) *reinterpret_cast<f32x4*>(yr + 4 * q) = (xv[j] - mu) * rs * wv[j] + bv[j];
+        }
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm backward.  dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * w.
 // Each wave walks rows (grid-stride) and keeps dw/db partial sums for its columns in registers;
@@ -515,7 +567,17 @@ extern "C" int vqh_layernorm_fwd(const float* x, int ldx, const float* w, const 
     if (rows == 0) return VQH_OK;
     VQH_CHECK_ARG(x && w && b && y, "vqh_layernorm_fwd: null pointer");
     const int grid = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, y, ldy, mean, rstd, rows, H, eps);
+    const bool vec = (H % 4 == 0) && H <= 1024 && ((ldx | ldy) % 4 == 0) &&
+                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) |
+                        reinterpret_cast<uintptr_t>(b)) & 15) == 0);
+    if (vec) {
+        const int gv = grid > 2048 ? 2048 : grid;            // grid-stride rows: weights stay in registers
+        if (H <= 256) hipLaunchKernelGGL((layernorm_fwd_vec_kernel<1>), dim3(gv), dim3(256), 0, stream, x, ldx, w, b, y, ldy, mean, rstd, rows, H, eps);
+        else if (H <= 512) hipLaunchKernelGGL((layernorm_fwd_vec_kernel<2>), dim3(gv), dim3(256), 0, stream, x, ldx, w, b, y, ldy, mean, rstd, rows, H, eps);
+        else hipLaunchKernelGGL((layernorm_fwd_vec_kernel<4>), dim3(gv), dim3(256), 0, stream, x, ldx, w, b, y, ldy, mean, rstd, rows, H, eps);
+    } else {
+        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, y, ldy, mean, rstd, rows, H, eps);
+    }
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
