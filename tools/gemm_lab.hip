@@ -60,8 +60,10 @@ __device__ unsigned long long* g_stamps = nullptr;      // diagnostic: [block][8
         g_stamps[(size_t)blockIdx.x * 8 + 4 + (slot)] = __builtin_amdgcn_s_memrealtime();              \
     }
 
+template <int EPI> struct LabFlags { static constexpr int ABL = (EPI >= 2) ? (EPI - 2) / 4 : 0; static constexpr bool LOADER = (ABL & 16) != 0; };
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_v2_nt(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__((WAVES_M* WAVES_N + (LabFlags<EPI>::LOADER ? 1 : 0)) * 64, 1) void gemm_v2_nt(const float* __restrict__ A, const float* __restrict__ B,
                                                                        float* __restrict__ C, int M, int N, int K, int lda,
                                                                        int ldb, int ldc) {
     using Cf = V2Cfg<WM, WN, WAVES_M, WAVES_N>;
@@ -145,12 +147,48 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_v2_nt(const flo
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
 
+    constexpr bool LOADER = LabFlags<EPI>::LOADER;
+    if (LOADER) {
+        // ---- wave NW is a pure loader: it issues ALL 48 DMA instructions of a tile, the compute waves carry no VMEM at all
+        if (wave == NW) {
+            const int lr = lane >> 3;
+            const int cc0 = (lane & 7) ^ ((lane >> 4) & 7), cc1 = (lane & 7) ^ ((4 + (lane >> 4)) & 7);
+            auto issue_full = [&](int kt, int stage) {
+                const unsigned sb = lds0 + stage * Cf::STAGE_BYTES;
+#pragma unroll
+                for (int j = 0; j < Cf::DMA_PER_STAGE; ++j) {
+                    const int R = j * 8 + lr;
+                    const int c = (j & 1) ? cc1 : cc0;
+                    const float* gp = (j * 8 < BM) ? A + (size_t)(m0 + R) * lda + c * 4 + (size_t)kt * BK
+                                                   : B + (size_t)(n0 + R - BM) * ldb + c * 4 + (size_t)kt * BK;
+                    glds16(gp, sb + j * 1024);
+                }
+            };
+            issue_full(0, 0);
+            issue_full(nk > 1 ? 1 : 0, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cf::DMA_PER_STAGE) : "memory");
+            __builtin_amdgcn_s_barrier();
+            int stage = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int nxt = (stage == 2) ? 0 : stage + 1;
+                const int nx2 = (nxt == 2) ? 0 : nxt + 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_full(min(kt + 2, nk - 1), nx2);
+                stage = nxt;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
     // ---- prologue: tiles 0 and 1 in flight, tile 0 landed and visible
     issue_tile(0, 0);
     if (nk > 1) issue_tile(1, 1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cf::DMA_PER_WAVE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    }
 
     STAMP(1)
     constexpr bool ILV = (EPI >= 2) ? (((EPI - 2) / 4) & 8) != 0 : (EPI == 1 || EPI == 0) ? false : false;
@@ -207,13 +245,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 1) void gemm_v2_nt(const flo
             sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 1>{}, I0{}, I0{}, 0, 0);
             sub_ilv(fa[1], fb[1], fa[0], fb[0], stage, std::integral_constant<int, 2>{}, I0{}, I0{}, 0, 0);
             if (!(ABL & 1)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!LOADER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
             // past the end the last tile is simply re-loaded into the free buffer (never read): no tail special case
             const int ktd = min(kt + 2, nk - 1);
-            sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 3>{}, I0{}, IH{}, ktd, nx2);
-            sub_ilv(fa[1], fb[1], fa[0], fb[0], nxt, I0{}, IH{}, IF{}, ktd, nx2);
+            if (LOADER) {
+                sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 3>{}, I0{}, I0{}, ktd, nx2);
+                sub_ilv(fa[1], fb[1], fa[0], fb[0], nxt, I0{}, I0{}, I0{}, ktd, nx2);
+            } else {
+                sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 3>{}, I0{}, IH{}, ktd, nx2);
+                sub_ilv(fa[1], fb[1], fa[0], fb[0], nxt, I0{}, IH{}, IF{}, ktd, nx2);
+            }
             stage = nxt;
             continue;
         }
@@ -317,7 +360,7 @@ static void run_v2(const float* A, const float* B, float* C, int M, int N, int K
         attr = true;
     }
     const int tiles = (M / Cf::BM) * (N / Cf::BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(Cf::NT), Cf::LDS_BYTES, st, A, B, C, M, N, K, K, K, N);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(Cf::NT + (LabFlags<EPI>::LOADER ? 64 : 0)), Cf::LDS_BYTES, st, A, B, C, M, N, K, K, K, N);
 }
 template <int WM, int WN, int WAVES_M, int WAVES_N>
 static bool ok_v2(int M, int N, int K) {
@@ -351,6 +394,7 @@ int main(int argc, char** argv) {
         {"v2 256x128 8w stamps noepi", run_v2<64, 64, 4, 2, 2>, ok_v2<64, 64, 4, 2>},
         {"4w stamps ILV", run_v2<128, 64, 2, 2, 2 + 4 * 8>, ok_v2<128, 64, 2, 2>},
         {"8w stamps ILV", run_v2<64, 64, 4, 2, 2 + 4 * 8>, ok_v2<64, 64, 4, 2>},
+        {"4w stamps ILV +loader wave", run_v2<128, 64, 2, 2, 2 + 4 * 24>, ok_v2<128, 64, 2, 2>},
         {"4w stamps ILV -barrier", run_v2<128, 64, 2, 2, 2 + 4 * 9>, ok_v2<128, 64, 2, 2>},
         {"4w stamps ILV -dma", run_v2<128, 64, 2, 2, 2 + 4 * 10>, ok_v2<128, 64, 2, 2>},
         {"4w stamps ILV -lds", run_v2<128, 64, 2, 2, 2 + 4 * 12>, ok_v2<128, 64, 2, 2>},
