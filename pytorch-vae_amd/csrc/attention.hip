@@ -519,6 +519,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnArgs
     }
 }
 
+#include "attention_small4.inc"
+
 // ---- short sequences: forward -----------------------------------------------------------------------
 // T <= 64 and S <= 64: one workgroup (2 waves) per (batch, head); Q, K, V staged once with coalesced 16-byte loads,
 // O leaves through LDS as whole rows (the general kernel's per-lane row-strided 4-byte stores touch 32-64 lines per
@@ -889,8 +891,31 @@ int launch_kv(void (*kernel)(const AttnArgs), dim3 grid, const AttnArgs& a, hipS
     return VQH_OK;
 }
 
+extern int g_attn_flags;
+
+template <int DH>
+int launch_bwd_small4(const AttnArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    constexpr int LD = DH + 4;
+    constexpr int VT = (64 * LD > 64 * 68) ? 64 * LD : 64 * 68;
+    const size_t smem = (size_t)(3 * 64 * LD + VT + 3 * 64) * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small4_kernel<DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            vqh_set_error(hipGetErrorString(e));
+            return VQH_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_small4_kernel<DH>), dim3(1, a.nh, a.B), dim3(256), smem, stream, a);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
 template <int DH>
 int launch_bwd_small(const AttnArgs& a, hipStream_t stream) {
+    if (!(g_attn_flags & 2)) return launch_bwd_small4<DH>(a, stream);      // bit 1: the two-group kernel of round 1 (A/B runs)
     static bool attr_set = false;
     const size_t smem = (size_t)(4 * 64 * (DH + 4) + 3 * 64) * sizeof(float);
     if (!attr_set) {
@@ -932,6 +957,15 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     a.drop = make_drop(rng_state, drop_site, drop_p);
     if (T <= 64 && S <= 64 && aligned16(O, ldo) && !(g_attn_flags & 1)) {
         dim3 grid(1, nh, B);
+        if (!(g_attn_flags & 2)) {                   // quartered form: 4 waves, one 32 x 32 quarter each
+            switch (dh) {
+                case 16: hipLaunchKernelGGL((attn_fwd_small4_kernel<16>), grid, dim3(256), 0, stream, a); break;
+                case 32: hipLaunchKernelGGL((attn_fwd_small4_kernel<32>), grid, dim3(256), 0, stream, a); break;
+                default: hipLaunchKernelGGL((attn_fwd_small4_kernel<64>), grid, dim3(256), 0, stream, a); break;
+            }
+            VQH_LAUNCH_CHECK();
+            return VQH_OK;
+        }
         switch (dh) {
             case 16: hipLaunchKernelGGL((attn_fwd_small_kernel<16>), grid, dim3(128), 0, stream, a); break;
             case 32: hipLaunchKernelGGL((attn_fwd_small_kernel<32>), grid, dim3(128), 0, stream, a); break;

@@ -19,7 +19,9 @@ Memory layout in HBM (all fp32, row-major):
   * residual-stream gradient: one [rows, H] buffer per stack, updated in place layer by layer
 """
 import collections
+import gc
 import os
+import weakref
 
 import torch
 
@@ -105,7 +107,10 @@ MAX_GRAPHS_PER_ARENA = 4
 class StepEngine:
     def __init__(self, model, seed=None):
         L.require_gpu()
-        self.m = model
+        # weak: the model owns the engine (VQVAE._eng); a strong back reference would make the pair a reference cycle, whose
+        # hipGraphs are then destroyed whenever the cycle collector happens to run -- e.g. in the middle of ANOTHER
+        # engine's stream capture, which aborts the process
+        self._model_ref = weakref.ref(model)
         self.dev = next(model.parameters()).device
         if self.dev.type != "cuda":
             raise L.VqhError("StepEngine: move the model to the GPU first (no CPU path exists)")
@@ -148,6 +153,13 @@ class StepEngine:
         self.share_layer0 = os.environ.get("VQH_SHARE_LAYER0", "1") != "0"
         # dropout backward of a residual branch written by the LayerNorm backward that produces its input (ln_bwd emit)
         self.fold_dropout_bwd = os.environ.get("VQH_FOLD_DROPOUT_BWD", "1") != "0"
+
+    @property
+    def m(self):
+        model = self._model_ref()
+        if model is None:
+            raise L.VqhError("StepEngine: its model has been deleted")
+        return model
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -1130,6 +1142,9 @@ class StepEngine:
         self.last_step_mode = "capture"
         torch.cuda.synchronize()
         segs = []
+        gc_was_on = gc.isenabled()
+        gc.disable()        # no cycle collection while a capture is open (torch.cuda.graph collects once on entry): a finaliser
+                            # that frees device memory or destroys another graph during capture aborts the process
         try:
             # thread_local: the RCCL watchdog thread may query events while this thread captures
             gen = self._step_gen(xs, xt, ms, weights, upd)
@@ -1158,6 +1173,9 @@ class StepEngine:
             self._pending_ema = None
             a.seen.pop(key, None)
             raise
+        finally:
+            if gc_was_on:
+                gc.enable()
         self._pending_ema = None
         a.graphs[key] = segs
         while len(a.graphs) > MAX_GRAPHS_PER_ARENA:
