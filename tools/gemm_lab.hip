@@ -237,6 +237,23 @@ __global__ __launch_bounds__((WAVES_M* WAVES_N + (LabFlags<EPI>::LOADER ? 1 : 0)
     for (int kt = 0; kt < nk; ++kt) {
         const int nxt = (stage == 2) ? 0 : stage + 1;
         const int nx2 = (nxt == 2) ? 0 : nxt + 1;
+        if (ILV && (ABL & 32) && wave >= NW / 2) {
+            // staggered half: barrier at the START of the K-step (these waves run half a step behind waves 0 .. NW/2-1, so a
+            // SIMD's two waves are never at the same point of the step: MI355X_MICROARCH.md, two waves per SIMD, item 9)
+            constexpr int HALF = Cf::DMA_PER_WAVE / 2;
+            using I0 = std::integral_constant<int, 0>;
+            using IH = std::integral_constant<int, HALF>;
+            using IF = std::integral_constant<int, Cf::DMA_PER_WAVE>;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int ktd = min(kt + 2, nk - 1);
+            sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 1>{}, I0{}, IH{}, ktd, nx2);
+            sub_ilv(fa[1], fb[1], fa[0], fb[0], stage, std::integral_constant<int, 2>{}, IH{}, IF{}, ktd, nx2);
+            sub_ilv(fa[0], fb[0], fa[1], fb[1], stage, std::integral_constant<int, 3>{}, I0{}, I0{}, 0, 0);
+            sub_ilv(fa[1], fb[1], fa[0], fb[0], nxt, I0{}, I0{}, I0{}, 0, 0);
+            stage = nxt;
+            continue;
+        }
         if (ILV) {
             constexpr int HALF = Cf::DMA_PER_WAVE / 2;
             using I0 = std::integral_constant<int, 0>;
@@ -395,6 +412,7 @@ int main(int argc, char** argv) {
         {"4w stamps ILV", run_v2<128, 64, 2, 2, 2 + 4 * 8>, ok_v2<128, 64, 2, 2>},
         {"8w stamps ILV", run_v2<64, 64, 4, 2, 2 + 4 * 8>, ok_v2<64, 64, 4, 2>},
         {"4w stamps ILV +loader wave", run_v2<128, 64, 2, 2, 2 + 4 * 24>, ok_v2<128, 64, 2, 2>},
+        {"8w stamps ILV +stagger", run_v2<64, 64, 4, 2, 2 + 4 * 40>, ok_v2<64, 64, 4, 2>},
         {"4w stamps ILV -barrier", run_v2<128, 64, 2, 2, 2 + 4 * 9>, ok_v2<128, 64, 2, 2>},
         {"4w stamps ILV -dma", run_v2<128, 64, 2, 2, 2 + 4 * 10>, ok_v2<128, 64, 2, 2>},
         {"4w stamps ILV -lds", run_v2<128, 64, 2, 2, 2 + 4 * 12>, ok_v2<128, 64, 2, 2>},
