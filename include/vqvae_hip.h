@@ -59,16 +59,30 @@ int vqh_gemm(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, 
 int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw,
                    float* db, float beta, float* workspace, long long workspace_floats, vqh_stream_t stream);
 
+/* All weight-gradient products of ONE transformer layer in one launch (each: dW = dY^T X, db = column sums of dY, beta 0):
+ * autograd's per-Linear weight-gradient GEMMs (models/vq_vae.py:455-533, one per nn.Linear / MHA projection) batched with a
+ * common K-chunk so that every workgroup runs a long K range and a tile needs few split-K slabs.  Products that do not tile
+ * evenly (n_out % 256, k_in % 128, rows % 32) are executed one by one exactly as vqh_gemm_wgrad would.  The operands must
+ * stay untouched until the call; workspace_floats >= sum over products of splits * (n_out * k_in + n_out). */
+typedef struct vqh_wgrad_t {
+    int rows, n_out, k_in;
+    const float* dY; int lddy;
+    const float* X; int ldx;
+    float* dW; int lddw;
+    float* db;                  /* may be null */
+} vqh_wgrad_t;
+int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* problems, float* workspace, long long workspace_floats, vqh_stream_t stream);
+
 /* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
  * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads);
  * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier; bit 6 = no skinny-shape
  * streaming kernels (everything on the MFMA tile kernel); bit 7 = no 256x128 LDS-DMA kernel (everything that tiles
- * evenly stays on the 128x128 register-staged kernel) */
+ * evenly stays on the 128x128 register-staged kernel); bit 8 = vqh_gemm_wgrad_group runs its products one by one */
 int vqh_gemm_set_flags(int flags);
 
 /* Live timing of the GEMM main kernels with HIP events on their launch stream (bench.py's roofline figure):
- * begin(), run eager (non-captured) steps, end(out) with out = double[2][4][9][3]: for kernel family (0 = gemm_f32_mfma,
- * the 128x128 register-staged tile; 1 = gemm_f32_dma, the 256x128 LDS-DMA tile), operand layout (a_kcontig*2 +
+ * begin(), run eager (non-captured) steps, end(out) with out = double[3][4][9][3]: for kernel family (0 = gemm_f32_mfma,
+ * the 128x128 register-staged tile; 1 = gemm_f32_dma, the 256x128 LDS-DMA tile; 2 = gemm_f32_dma_group, one entry per launch), operand layout (a_kcontig*2 +
  * b_kcontig) and kernel template MODE+1 (0 = generic kernel, 1.. = epilogue-specialised): launches, kernel seconds,
  * sum of 2*M*N*K.  The split-K reduce launch is not inside the bracket. */
 int vqh_gemm_profile_begin(void);

@@ -21,6 +21,7 @@
 #include "common.h"
 #include <type_traits>
 #include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -676,7 +677,7 @@ struct ProfRec { int slot; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 constexpr int PROF_MODES = 9;                       // template MODE -1..7 -> column MODE+1
-constexpr int PROF_FAMILIES = 2;                    // 0 = gemm_f32_mfma (128x128 tile), 1 = gemm_f32_dma (256x128 tile)
+constexpr int PROF_FAMILIES = 3;                    // 0 = gemm_f32_mfma (128x128 tile), 1 = gemm_f32_dma (256x128 tile), 2 = gemm_f32_dma_group
 inline int prof_slot(bool a_kc, bool b_kc, int mode_t, int family = 0) {
     return (family * 4 + (a_kc ? 2 : 0) + (b_kc ? 1 : 0)) * PROF_MODES + mode_t + 1;
 }
@@ -756,7 +757,7 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t stream) {
 }  // namespace
 
 // Timing of every GEMM main-kernel launch between begin and end (not under stream capture).  end() synchronises
-// the recorded events and fills out[2][4][9][3]: per (kernel family 0 = gemm_f32_mfma / 1 = gemm_f32_dma, operand layout
+// the recorded events and fills out[3][4][9][3]: per (kernel family 0 = gemm_f32_mfma / 1 = gemm_f32_dma / 2 = gemm_f32_dma_group, operand layout
 // a_kc*2+b_kc, template MODE+1) the number of
 // launches, the summed kernel seconds and the summed 2*M*N*K.  The split-K reduce launch is outside the bracket.
 extern "C" int vqh_gemm_profile_begin(void) {
@@ -1006,4 +1007,138 @@ extern "C" int vqh_gemm_wgrad(int rows, int n_out, int k_in, const float* dY, in
     if (rows > 0 && n_out > 0 && k_in == 0) return VQH_OK;
     return gemm_impl(0, 0, n_out, k_in, rows, dY, lddy, X, ldx, dW, lddw, nullptr, EPI_LINEAR, nullptr, nullptr, 0, beta,
                      nullptr, 0, 0.f, workspace, workspace_floats, db, stream);
+}
+
+// All weight-gradient products of one layer in one launch (see gemm_f32_dma_group).  Every problem is dW = dY^T X with
+// db = column sums of dY, written with beta = 0.  Products that do not tile evenly run one by one through vqh_gemm_wgrad.
+struct vqh_wgrad_t {
+    int rows, n_out, k_in;
+    const float* dY; int lddy;
+    const float* X; int ldx;
+    float* dW; int lddw;
+    float* db;
+};
+extern "C" int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* pr, float* workspace, long long workspace_floats,
+                                    hipStream_t stream) {
+    VQH_CHECK_ARG(n >= 0 && (n == 0 || pr), "vqh_gemm_wgrad_group: bad argument");
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    std::vector<int> big;
+    for (int i = 0; i < n; ++i) {
+        const vqh_wgrad_t& w = pr[i];
+        VQH_CHECK_ARG(w.rows >= 0 && w.n_out >= 0 && w.k_in >= 0, "vqh_gemm_wgrad_group: negative dimension");
+        const bool ok = !(g_gemm_flags & (128 | 256)) && workspace && w.rows >= 8 * dma::TBK && (w.rows % dma::TBK) == 0 &&
+                        (w.n_out % dma::TBM) == 0 && (w.k_in % dma::TBN) == 0 && w.n_out > 0 && w.k_in > 0 && al16(w.dY) &&
+                        al16(w.X) && al16(w.dW) && al16(workspace) && (w.lddy & 3) == 0 && (w.ldx & 3) == 0 && (w.lddw & 3) == 0 &&
+                        w.lddy >= w.n_out && w.ldx >= w.k_in && w.lddw >= w.k_in;
+        if (ok) {
+            big.push_back(i);
+        } else {
+            const int rc = vqh_gemm_wgrad(w.rows, w.n_out, w.k_in, w.dY, w.lddy, w.X, w.ldx, w.dW, w.lddw, w.db, 0.f, workspace,
+                                          workspace_floats, stream);
+            if (rc != VQH_OK) return rc;
+        }
+    }
+    for (size_t c0 = 0; c0 < big.size(); c0 += GROUP_MAX) {
+        const int m = (int)std::min<size_t>(GROUP_MAX, big.size() - c0);
+        // common K-chunk: maximise (CU utilisation of the last round) x (share of a workgroup's time spent in K-steps)
+        long long tiles_tot = 0;
+        int kmax = 0;
+        for (int j = 0; j < m; ++j) {
+            const vqh_wgrad_t& w = pr[big[c0 + j]];
+            tiles_tot += (long long)(w.n_out / dma::TBM) * (w.k_in / dma::TBN);
+            kmax = std::max(kmax, w.rows);
+        }
+        int best_kc = kmax;
+        double best = -1.0;
+        for (int sp = 1; sp <= 64; ++sp) {
+            const int kc = ((kmax + sp - 1) / sp + dma::TBK - 1) / dma::TBK * dma::TBK;
+            if (kc < 16 * dma::TBK && sp > 1) break;
+            long long wgs = 0, slab = 0;
+            for (int j = 0; j < m; ++j) {
+                const vqh_wgrad_t& w = pr[big[c0 + j]];
+                const int splits = (w.rows + kc - 1) / kc;
+                wgs += (long long)(w.n_out / dma::TBM) * (w.k_in / dma::TBN) * splits;
+                if (splits > 1) slab += (long long)splits * ((long long)w.n_out * w.k_in + w.n_out);
+            }
+            if (slab > workspace_floats) continue;
+            const double rounds = (double)((wgs + 255) / 256);
+            const double util = (double)wgs / (256.0 * rounds);
+            const double score = util * (double)kc / ((double)kc + 12.0 * dma::TBK);     // ~12 K-steps of fixed cost per workgroup
+            if (score > best) { best = score; best_kc = kc; }
+        }
+        GemmGroupArgs G;
+        G.n = m;
+        int wg = 0;
+        long long off = 0;
+        double flops = 0.0;
+        struct Red { float* ws; int splits, M, N; float* C; int ldc; float* rs_ws; float* rowsum; };
+        Red red[GROUP_MAX];
+        int nred = 0;
+        for (int j = 0; j < m; ++j) {
+            const vqh_wgrad_t& w = pr[big[c0 + j]];
+            GemmArgs& g = G.p[j];
+            g.A = w.dY; g.B = w.X; g.C = w.dW;
+            g.M = w.n_out; g.N = w.k_in; g.K = w.rows;
+            g.lda = w.lddy; g.ldb = w.ldx; g.ldc = w.lddw;
+            g.kchunk = best_kc;
+            g.vecA = g.vecB = g.vecC = 1;
+            g.mode = EPI_LINEAR; g.bias = nullptr; g.aux_in = nullptr; g.aux_out = nullptr; g.ldaux = 0; g.beta = 0.f;
+            g.drop = make_drop(nullptr, 0, 0.f);
+            g.flags = g_gemm_flags;
+            g.rowsum = w.db;
+            const int splits = (w.rows + best_kc - 1) / best_kc;
+            if (splits > 1) {
+                g.ws = workspace + off;
+                off += (long long)splits * w.n_out * w.k_in;
+                g.rowsum_ws = w.db ? workspace + off : nullptr;
+                if (w.db) off += (long long)splits * w.n_out;
+                off = (off + 3) / 4 * 4;
+                red[nred++] = Red{g.ws, splits, w.n_out, w.k_in, w.dW, w.lddw, g.rowsum_ws, w.db};
+            } else {
+                g.ws = nullptr;
+                g.rowsum_ws = nullptr;
+            }
+            G.tiles[j] = (w.n_out / dma::TBM) * (w.k_in / dma::TBN);
+            G.wg_begin[j] = wg;
+            wg += G.tiles[j] * splits;
+            flops += 2.0 * w.n_out * (double)w.k_in * w.rows;
+        }
+        for (int j = m; j <= GROUP_MAX; ++j) G.wg_begin[j] = wg;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma_group),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, dma::LDS_BYTES);
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+            attr_set = true;
+        }
+        ProfRec rec{};
+        if (g_prof_on) {
+            rec.slot = prof_slot(false, false, EPI_LINEAR, 2);
+            rec.flops = flops;
+            if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess ||
+                hipEventRecord(rec.e0, stream) != hipSuccess) {
+                vqh_set_error("vqh_gemm_wgrad_group: profiling events failed");
+                return VQH_ERR_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL(gemm_f32_dma_group, dim3(wg), dim3(256), dma::LDS_BYTES, stream, G);
+        VQH_LAUNCH_CHECK();
+        if (g_prof_on) {
+            if (hipEventRecord(rec.e1, stream) != hipSuccess) {
+                vqh_set_error("vqh_gemm_wgrad_group: profiling events failed");
+                return VQH_ERR_LAUNCH;
+            }
+            g_prof.push_back(rec);
+        }
+        for (int j = 0; j < nred; ++j) {
+            const Red& r = red[j];
+            int blocks = (int)(((size_t)r.M * r.N / 4 + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            if (r.rowsum && blocks < (r.M + 255) / 256) blocks = (r.M + 255) / 256;
+            hipLaunchKernelGGL(splitk_reduce_vec, dim3(blocks), dim3(256), 0, stream, r.ws, r.splits, r.M, r.N, r.C, r.ldc,
+                               (const float*)nullptr, 0.f, r.rs_ws, r.rowsum);
+        }
+        VQH_LAUNCH_CHECK();
+    }
+    return VQH_OK;
 }

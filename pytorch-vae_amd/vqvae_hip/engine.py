@@ -153,6 +153,11 @@ class StepEngine:
         self.share_layer0 = os.environ.get("VQH_SHARE_LAYER0", "1") != "0"
         # dropout backward of a residual branch written by the LayerNorm backward that produces its input (ln_bwd emit)
         self.fold_dropout_bwd = os.environ.get("VQH_FOLD_DROPOUT_BWD", "1") != "0"
+        # weight gradients of a transformer layer are queued and run as ONE grouped launch when the layer's backward is
+        # done (vqh_gemm_wgrad_group): long K ranges per workgroup and few split-K slabs instead of 4-7 short launches
+        self.group_wgrad = os.environ.get("VQH_GROUP_WGRAD", "1") != "0"
+        self._wq = []
+        self._dy_slot = 0
 
     @property
     def m(self):
@@ -281,12 +286,36 @@ class StepEngine:
 
     def lin_wgrad(self, dy, lddy, x, ldx, rows, gW, gb):
         N, K = gW.shape         # gW[N,K] = dy[rows,N]^T . x[rows,K] ; gb[N] = column sums of dy (same launch)
+        if self.group_wgrad:
+            # deferred to flush_wgrads(): dy and x must stay untouched until then -- dy buffers come from dy_tag() (a fresh
+            # one per block), saved activations are never written in backward (the FFN keeps d(pre-activation) apart)
+            self._wq.append((dy, lddy, x, ldx, rows, gW, gb))
+            return
         call("vqh_gemm_wgrad", rows, N, K, dy, lddy, x, ldx, gW, K, gb, 0.0, self.ws, self.ws.numel())
+
+    def flush_wgrads(self):
+        """Run the queued weight-gradient products of the layer just finished as one grouped launch."""
+        if self._wq:
+            L.wgrad_group(self._wq, self.ws)
+            self._wq = []
+        self._dy_slot = 0
+
+    def dy_tag(self):
+        """Name of a fresh buffer for a block's output gradient (valid until the next flush_wgrads)."""
+        t = f"tmp.dy{self._dy_slot}"
+        self._dy_slot += 1
+        return t
 
     def drop_bwd(self, dy, n, site, p, tag):
         """dy * keep-mask of a DROP_RESID site (identity when p == 0)."""
         if p <= 0.0:
-            return dy
+            if not self.group_wgrad:
+                return dy
+            # the residual-stream gradient is updated in place later in the block, but a deferred weight-gradient product
+            # still reads this value: give it its own copy
+            out = self.T(tag, n)
+            call("vqh_copy2d", dy, n, out, n, 1, n)
+            return out
         out = self.T(tag, n)
         call("vqh_dropout_bwd", dy, out, n, self.rng, site, p)
         return out
@@ -381,7 +410,7 @@ class StepEngine:
         self_attn = mem is None
         h = self.buf[f"{pre}.{norm}.y"]
         # dy_in: dres * mask already written by the LayerNorm backward that produced dres (ln_bwd emit)
-        dy = dy_in if dy_in is not None else self.drop_bwd(dres, rows * H, self.site(a + ".drop"), self.pdrop(p), "tmp.dy")
+        dy = dy_in if dy_in is not None else self.drop_bwd(dres, rows * H, self.site(a + ".drop"), self.pdrop(p), self.dy_tag())
         self.lin_wgrad(dy, H, self.buf[a + ".ao"], H, rows, self.G[a + ".out_proj.weight"], self.G[a + ".out_proj.bias"])
         d_ao = self.T("tmp.dao", rows, H)
         self.lin_dgrad(dy, H, rows, self.P[a + ".out_proj.weight"], d_ao, H)
@@ -420,12 +449,13 @@ class StepEngine:
         f1 = self.buf[f"{pre}.{lin1}.y"]
         h = self.buf[f"{pre}.{norm}.y"]
         dy = dy_in if dy_in is not None else self.drop_bwd(dres, rows * H, self.site(f"{pre}.{lin2}.drop"), self.pdrop(p_out),
-                                                           "tmp.dy")
+                                                           self.dy_tag())
         self.lin_wgrad(dy, H, f1, F, rows, self.G[f"{pre}.{lin2}.weight"], self.G[f"{pre}.{lin2}.bias"])
         if act == "relu":
-            # d pre-activation, written over the saved post-activation (read-then-write per element)
-            self.lin_dgrad(dy, H, rows, W2, f1, F, mode=L.EPI_MUL_POSMASK, aux_in=f1, ldaux=F, p=self.pdrop(p_inner))
-            dpre = f1
+            # d pre-activation: written over the saved post-activation (read-then-write per element), unless the weight
+            # gradient of linear2 -- which needs that activation -- is deferred to the layer's grouped launch
+            dpre = self.T("tmp.dpre", rows, F) if self.group_wgrad else f1
+            self.lin_dgrad(dy, H, rows, W2, dpre, F, mode=L.EPI_MUL_POSMASK, aux_in=f1, ldaux=F, p=self.pdrop(p_inner))
         else:
             dpre = self.buf[f"{pre}.{lin1}.pre"]
             self.lin_dgrad(dy, H, rows, W2, dpre, F, mode=L.EPI_MUL_GELUGRAD, aux_in=dpre, ldaux=F)
@@ -514,11 +544,13 @@ class StepEngine:
         for i in reversed(range(n_layers)):
             pre = f"{stack}.layers.{i}"
             dy = self.ffn_block_bwd(pre, "norm2", "linear1", "linear2", xs[2 * i + 1], dres, ML, "relu", 0.1, 0.1, dy_in=dy,
-                                    emit=(self.site(f"{pre}.self_attn.drop"), self.pdrop(0.1), "tmp.dy"))
+                                    emit=(self.site(f"{pre}.self_attn.drop"), self.pdrop(0.1), self.dy_tag()))
             nxt = None
             if i > 0:
-                nxt = (self.site(f"{stack}.layers.{i - 1}.linear2.drop"), self.pdrop(0.1), "tmp.dy")
+                # consumed by the NEXT layer's first block, i.e. after this layer's flush: outside the per-layer rotation
+                nxt = (self.site(f"{stack}.layers.{i - 1}.linear2.drop"), self.pdrop(0.1), f"tmp.dy_carry{i & 1}")
             dy = self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask, dy_in=dy, emit=nxt)
+            self.flush_wgrads()
             yield i                                   # layer i's gradients are final
 
     def encode_bwd_geo(self):
@@ -592,7 +624,7 @@ class StepEngine:
             pre = f"tokenizer.layers.{i}"
             a = pre + ".attn"
             self.ffn_block_bwd(pre, "ln_o", "ffn.0", "ffn.2", qs[2 * i + 1], dres, MN, "gelu", 0.0, pd)
-            dy = self.drop_bwd(dres, MN * H, self.site(pre + ".drop"), self.pdrop(pd), "tmp.dy_tok")
+            dy = self.drop_bwd(dres, MN * H, self.site(pre + ".drop"), self.pdrop(pd), self.dy_tag())
             self.lin_wgrad(dy, H, self.buf[a + ".ao"], H, MN, self.G[a + ".out_proj.weight"], self.G[a + ".out_proj.bias"])
             d_ao = self.T("tmp.dao_tok", MN, H)
             self.lin_dgrad(dy, H, MN, self.P[a + ".out_proj.weight"], d_ao, H)
@@ -606,6 +638,8 @@ class StepEngine:
             else:
                 self.ln_bwd(pre + ".ln_q", dqn, H, qs[2 * i], H, pre + ".ln_q", dres, H, True, MN)
             self.ln_bwd(pre + ".ln_kv", dkvn, H, self.buf["fuse.out"], H, pre + ".ln_kv", d_hf, H, i != nl - 1, ML)
+            self.flush_wgrads()
+        self.flush_wgrads()
         gq = self.G["tokenizer.queries"]
         call("vqh_colsum", dres, N * H, B, N * H, gq, 0.0, self.ws, self.ws.numel())
         if self.share_layer0 and nl > 0:
@@ -820,12 +854,12 @@ class StepEngine:
         for i in reversed(range(nl)):
             pre = f"decoder.layers.{i}"
             dy = self.ffn_block_bwd(pre, "norm3", "linear1", "linear2", xs[3 * i + 2], dres, ML, "relu", 0.1, 0.1, dy_in=dy,
-                                    emit=(self.site(f"{pre}.multihead_attn.drop"), pd, "tmp.dy"))
+                                    emit=(self.site(f"{pre}.multihead_attn.drop"), pd, self.dy_tag()))
             dy = self.attn_block_bwd(pre, "multihead_attn", "norm2", xs[3 * i + 1], dres, ML, B, Lq, self.nh, None, mem=mem,
                                      rows_kv=MN, S=Nmem, d_mem=d_mem, mem_beta=0.0 if i == nl - 1 else 1.0, dy_in=dy,
-                                     emit=(self.site(f"{pre}.self_attn.drop"), pd, "tmp.dy"))
+                                     emit=(self.site(f"{pre}.self_attn.drop"), pd, self.dy_tag()))
             sh0 = self.share_layer0 and i == 0
-            nxt = (self.site(f"decoder.layers.{i - 1}.linear2.drop"), pd, "tmp.dy") if i > 0 else None
+            nxt = (self.site(f"decoder.layers.{i - 1}.linear2.drop"), pd, f"tmp.dy_carry{i & 1}") if i > 0 else None
             out = self.attn_block_bwd(pre, "self_attn", "norm1", xs[3 * i], dres, ML, B, Lq, self.nh, mask, shared=sh0,
                                       dy_in=dy, emit=None if sh0 else nxt)
             if sh0:
@@ -833,6 +867,7 @@ class StepEngine:
             else:
                 dy = out
             if i > 0:
+                self.flush_wgrads()
                 yield i
         # tgt = query_embed[:L] + pos_enc[:L] broadcast over the batch
         gq = self.G["query_embed.weight"]
@@ -844,6 +879,7 @@ class StepEngine:
         self.ln_bwd("mem_ln", d_mem, H, self.buf["dec.memf"], H, "mem_ln", dmemf, H, False, MN)
         self.lin_wgrad(dmemf, H, c["dec_z"], D, MN, self.G["from_code.weight"], self.G["from_code.bias"])
         self.lin_dgrad(dmemf, H, MN, self.P["from_code.weight"], d_z, D, beta=z_beta)
+        self.flush_wgrads()
         yield 0
 
     # ------------------------------------------------------------------ whole step
@@ -986,8 +1022,10 @@ class StepEngine:
         for _ in self.decode_bwd_gen(c["d_rec"], c["d_ze"], 1.0 if self.m.use_vq else 0.0):
             yield
         c["d_hf"] = self.tokenize_bwd(c["d_ze"])
+        self.flush_wgrads()
         yield
         self.encode_bwd_ss(c["d_hf"])
+        self.flush_wgrads()
         yield
         for _ in self.encode_bwd_geo():
             yield
@@ -1116,7 +1154,7 @@ class StepEngine:
         # everything a captured graph bakes in as a kernel argument (the batch shape is the arena)
         key = (mask is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
                world, dp, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0),
-               x_in is xt, float(m.usage_entropy_lambda), self._soft_vq_key(), self.share_layer0, self.fold_dropout_bwd,
+               x_in is xt, float(m.usage_entropy_lambda), self._soft_vq_key(), self.share_layer0, self.fold_dropout_bwd, self.group_wgrad,
                float(m.xyz_align_alpha), float(m.ss_tv_lambda), m._data_std is not None)
         xs = x_in
         ms = None

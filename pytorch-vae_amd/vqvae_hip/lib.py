@@ -24,6 +24,7 @@ _PROTOS = {
     "vqh_memset": "pilp",
     "vqh_gemm": "iiiiipipipipippifpufplp",
     "vqh_gemm_wgrad": "iiipipipipfplp",
+    "vqh_gemm_wgrad_group": "ipplp",
     "vqh_layernorm_fwd": "pipppippiifp",
     "vqh_layernorm_bwd": "pipippppiippfiippufplp",
     "vqh_reduce_slabs": "pillpfp",
@@ -113,19 +114,19 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, mode=EPI_LIN
 def gemm_profile(fn):
     """Run fn() with the library's per-launch GEMM timing on; returns {(family, a_kc, b_kc, MODE): (launches, seconds, flops)}
     keyed like the kernels' template arguments: family 0 = gemm_f32_mfma<a_kc, b_kc, 32, MODE> (128x128 tile),
-    family 1 = gemm_f32_dma<a_kc, b_kc, MODE> (256x128 tile, LDS-DMA)."""
+    family 1 = gemm_f32_dma<a_kc, b_kc, MODE> (256x128 tile, LDS-DMA), family 2 = gemm_f32_dma_group (grouped weight gradients)."""
     import ctypes
     lib().vqh_gemm_profile_begin()
     try:
         fn()
         torch.cuda.synchronize()
     finally:
-        out = (ctypes.c_double * (2 * 4 * 9 * 3))()
+        out = (ctypes.c_double * (3 * 4 * 9 * 3))()
         rc = lib().vqh_gemm_profile_end(ctypes.cast(out, ctypes.c_void_p))
     if rc != 0:
         raise VqhError(f"vqh_gemm_profile_end failed: {lib().vqh_last_error().decode()}")
     res = {}
-    for fam in range(2):
+    for fam in range(3):
         for lay in range(4):
             for mc in range(9):
                 o = ((fam * 4 + lay) * 9 + mc) * 3
@@ -155,7 +156,28 @@ def gemm_kernel_name(key):
     tf = lambda b: "true" if b else "false"
     if fam == 0:
         return "gemm_f32_mfma<%s, %s, 32, %d>" % (tf(a_kc), tf(b_kc), mode)
+    if fam == 2:
+        return "gemm_f32_dma_group"
     return "gemm_f32_dma<%s, %s, %d>" % (tf(a_kc), tf(b_kc), mode)
+
+
+class WgradT(C.Structure):
+    """vqh_wgrad_t of include/vqvae_hip.h"""
+    _fields_ = [("rows", C.c_int), ("n_out", C.c_int), ("k_in", C.c_int), ("dY", C.c_void_p), ("lddy", C.c_int),
+                ("X", C.c_void_p), ("ldx", C.c_int), ("dW", C.c_void_p), ("lddw", C.c_int), ("db", C.c_void_p)]
+
+
+def wgrad_group(items, ws):
+    """items: [(dY, lddy, X, ldx, rows, dW [n_out, k_in], db or None)] -> one grouped weight-gradient launch."""
+    n = len(items)
+    if n == 0:
+        return
+    arr = (WgradT * n)()
+    for i, (dy, lddy, x, ldx, rows, gW, gb) in enumerate(items):
+        n_out, k_in = gW.shape
+        arr[i] = WgradT(int(rows), int(n_out), int(k_in), dy.data_ptr(), int(lddy), x.data_ptr(), int(ldx), gW.data_ptr(),
+                        int(gW.stride(0)), _p(gb))
+    call("vqh_gemm_wgrad_group", n, C.cast(arr, C.c_void_p), ws, ws.numel())
 
 
 def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws):

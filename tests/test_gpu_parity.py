@@ -86,6 +86,35 @@ def test_gemm_wgrad_weight_and_bias_gradients(rows, n_out, k_in):
     assert rel(dW2, ref_w) < 3e-6
 
 
+def test_grouped_weight_gradients_match_fp64():
+    """vqh_gemm_wgrad_group: the weight-gradient products of one layer in ONE launch with a common K-chunk (evenly tiled
+    products grouped, the others executed one by one), against fp64; bit 8 of the GEMM flags runs everything one by one."""
+    L = _hip()
+    torch.manual_seed(11)
+    rows = 4096
+    shapes = [(1536, 512), (512, 512), (2048, 512), (512, 2048), (64, 512), (3, 512), (1024, 512), (512, 1024), (256, 128), (512, 512)]
+    ws = torch.empty(48 << 20, device=DEV)
+    for flags in (1, 1 | 256):
+        old = L.lib().vqh_gemm_set_flags(flags)
+        try:
+            items, refs = [], []
+            for i, (n_out, k_in) in enumerate(shapes):
+                r = rows if i != 6 else 1024                      # one product with a shorter reduction
+                dY, X = torch.randn(r, n_out, device=DEV), torch.randn(r, k_in, device=DEV)
+                dW = torch.full((n_out, k_in), float("nan"), device=DEV)
+                db = torch.full((n_out,), float("nan"), device=DEV) if i % 3 != 2 else None
+                items.append((dY, n_out, X, k_in, r, dW, db))
+                refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
+            L.wgrad_group(items, ws)
+            torch.cuda.synchronize()
+            for (dY, _, X, _, r, dW, db), (rw, rb) in zip(items, refs):
+                assert rel(dW, rw) < 3e-6, dW.shape
+                if db is not None:
+                    assert rel(db, rb) < 3e-6, dW.shape
+        finally:
+            L.lib().vqh_gemm_set_flags(old)
+
+
 def test_gemm_accumulate_into_output():
     """beta = 1 (second head's input gradient added to the first, decode_bwd) on the MFMA and the skinny path."""
     L = _hip()
