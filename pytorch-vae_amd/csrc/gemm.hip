@@ -554,6 +554,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict
     }
 }
 
+// The split-K reductions of a grouped weight-gradient launch in ONE kernel: blockIdx.y selects the product.
+struct RedGroupArgs {
+    int n;
+    struct Item { const float* ws; int splits, M, N; float* C; int ldc; const float* rs_ws; float* rowsum; } r[8];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_group(const RedGroupArgs G) {
+    const RedGroupArgs::Item& it = G.r[blockIdx.y];
+    const int S = it.splits, M = it.M, N = it.N;
+    const size_t total = (size_t)M * N, quads = total >> 2;
+    if (it.rowsum) {
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int z = 0; z < S; ++z) s += it.rs_ws[(size_t)z * M + m];
+            it.rowsum[m] = s;
+        }
+    }
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+        const float* src = it.ws + q * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= S; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(z + u) * total);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < S; ++z) s += *reinterpret_cast<const f32x4*>(src + (size_t)z * total);
+        const size_t e = q * 4;
+        const int row = (int)(e / N), col = (int)(e % N);
+        *reinterpret_cast<f32x4*>(it.C + (size_t)row * it.ldc + col) = s;
+    }
+}
+
 // ---- skinny shapes: the reconstruction heads (512 -> 3, models/vq_vae.py:763-764) ---------------------------------------
 // A 128x128 MFMA tile with 3 live columns wastes 98 % of the matrix work (60-90 us per launch); these shapes are pure
 // streaming of the wide operand (33 MB at C2) and run at HBM speed in simple kernels instead.  SK_MAX = largest small
@@ -1130,13 +1164,17 @@ extern "C" int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* pr, float* workspa
             }
             g_prof.push_back(rec);
         }
-        for (int j = 0; j < nred; ++j) {
-            const Red& r = red[j];
-            int blocks = (int)(((size_t)r.M * r.N / 4 + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            if (r.rowsum && blocks < (r.M + 255) / 256) blocks = (r.M + 255) / 256;
-            hipLaunchKernelGGL(splitk_reduce_vec, dim3(blocks), dim3(256), 0, stream, r.ws, r.splits, r.M, r.N, r.C, r.ldc,
-                               (const float*)nullptr, 0.f, r.rs_ws, r.rowsum);
+        if (nred > 0) {
+            RedGroupArgs RG;
+            RG.n = nred;
+            int blocks = 1;
+            for (int j = 0; j < nred; ++j) {
+                const Red& r = red[j];
+                RG.r[j] = RedGroupArgs::Item{r.ws, r.splits, r.M, r.N, r.C, r.ldc, r.rs_ws, r.rowsum};
+                blocks = std::max(blocks, (int)(((size_t)r.M * r.N / 4 + 255) / 256));
+            }
+            if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(splitk_reduce_group, dim3(blocks, nred), dim3(256), 0, stream, RG);
         }
         VQH_LAUNCH_CHECK();
     }

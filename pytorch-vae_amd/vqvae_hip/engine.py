@@ -530,17 +530,20 @@ class StepEngine:
         # ---- secondary-structure branch
         xs = c["ss_xs"]
         dres = self.T("tmp.dres_seq", ML, H)
-        self.ln_bwd("ln_ss", dcat[:, H:], 2 * H, xs[-1], H, "ln_ss", dres, H, False, ML)
-        for _ in self._encoder_stack_bwd("ss_encoder", SS_LAYERS, xs, dres, ML, B, Lq, mask):
+        dy0 = self.ln_bwd("ln_ss", dcat[:, H:], 2 * H, xs[-1], H, "ln_ss", dres, H, False, ML,
+                          emit=(self.site(f"ss_encoder.layers.{SS_LAYERS - 1}.linear2.drop"), self.pdrop(0.1), "tmp.dy_carry_in")
+                          if SS_LAYERS > 0 else None)
+        for _ in self._encoder_stack_bwd("ss_encoder", SS_LAYERS, xs, dres, ML, B, Lq, mask, dy0=dy0):
             pass
         call("vqh_embed_bwd", dres, c["x"], 6, 3, self.G["ss_input_proj.weight"], self.G["ss_input_proj.bias"], 0.0, ML, H,
              self.rng, 0, 0.0, self.ws, self.ws.numel())
 
-    def _encoder_stack_bwd(self, stack, n_layers, xs, dres, ML, B, Lq, mask):
+    def _encoder_stack_bwd(self, stack, n_layers, xs, dres, ML, B, Lq, mask, dy0=None):
         """Backward through n_layers pre-LN encoder layers.  Every block ends in a LayerNorm backward that accumulates into
         dres; it also emits dres * mask of the dropout site that opens the NEXT block (in backward order), so only the
-        first block of the stack runs the stand-alone dropout-backward pass."""
-        dy = None
+        first block of the stack runs the stand-alone dropout-backward pass -- unless the caller's own LayerNorm backward
+        already emitted it (dy0)."""
+        dy = dy0
         for i in reversed(range(n_layers)):
             pre = f"{stack}.layers.{i}"
             dy = self.ffn_block_bwd(pre, "norm2", "linear1", "linear2", xs[2 * i + 1], dres, ML, "relu", 0.1, 0.1, dy_in=dy,
@@ -562,9 +565,12 @@ class StepEngine:
         xs = c["geo_xs"]
         dhg = self.T("tmp.dh", ML, H)
         self.ln_bwd("ln_geo", dcat, 2 * H, self.buf["enc_ln.y"], H, "ln_geo", dhg, H, False, ML)
-        self.ln_bwd("enc_ln", dhg, H, xs[-1], H, "enc_ln", dres, H, False, ML)
+        nl = self.m.num_layers
+        dy0 = self.ln_bwd("enc_ln", dhg, H, xs[-1], H, "enc_ln", dres, H, False, ML,
+                          emit=(self.site(f"encoder.layers.{nl - 1}.linear2.drop"), self.pdrop(0.1), "tmp.dy_carry_in")
+                          if nl > 0 else None)
         embed_done = False
-        for i in self._encoder_stack_bwd("encoder", self.m.num_layers, xs, dres, ML, B, Lq, mask):
+        for i in self._encoder_stack_bwd("encoder", nl, xs, dres, ML, B, Lq, mask, dy0=dy0):
             if i == 0:                                # input_proj belongs to the last phase
                 call("vqh_embed_bwd", dres, c["x"], 6, 0, self.G["input_proj.weight"], self.G["input_proj.bias"], 0.0, ML, H,
                      self.rng, self.site("inp_dropout"), self.pdrop(0.1), self.ws, self.ws.numel())
@@ -623,8 +629,10 @@ class StepEngine:
         for i in reversed(range(nl)):
             pre = f"tokenizer.layers.{i}"
             a = pre + ".attn"
-            self.ffn_block_bwd(pre, "ln_o", "ffn.0", "ffn.2", qs[2 * i + 1], dres, MN, "gelu", 0.0, pd)
-            dy = self.drop_bwd(dres, MN * H, self.site(pre + ".drop"), self.pdrop(pd), self.dy_tag())
+            dy = self.ffn_block_bwd(pre, "ln_o", "ffn.0", "ffn.2", qs[2 * i + 1], dres, MN, "gelu", 0.0, pd,
+                                    emit=(self.site(pre + ".drop"), self.pdrop(pd), self.dy_tag()))
+            if dy is None:
+                dy = self.drop_bwd(dres, MN * H, self.site(pre + ".drop"), self.pdrop(pd), self.dy_tag())
             self.lin_wgrad(dy, H, self.buf[a + ".ao"], H, MN, self.G[a + ".out_proj.weight"], self.G[a + ".out_proj.bias"])
             d_ao = self.T("tmp.dao_tok", MN, H)
             self.lin_dgrad(dy, H, MN, self.P[a + ".out_proj.weight"], d_ao, H)
