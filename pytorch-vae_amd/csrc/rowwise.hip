@@ -4,6 +4,7 @@
 // Reference call sites: nn.LayerNorm instances /root/reference/models/vq_vae.py:462-465,501,524 and the
 // per-layer norms; input_proj/ss_input_proj + pos_enc :642-650; query_embed + pos_enc :750-751.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -602,7 +603,16 @@ extern "C" int vqh_layernorm_bwd(const float* dy, int lddy, const float* x, int 
     VQH_CHECK_ARG(dy && x && w && mean && rstd && dx && dw && db && workspace, "vqh_layernorm_bwd: null pointer");
     VQH_CHECK_ARG(!dx_drop || (rng_state && drop_p > 0.f && drop_p < 1.f), "vqh_layernorm_bwd: dx_drop needs rng_state and 0 < p < 1");
     int nblk = (rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    if (nblk > 1024) nblk = 1024;
+    {   // workgroups = partial-sum slabs the second kernel has to read: 1024 (measured: 512 the same, 256 +0.6 ms per step) for this
+        // memory-bound kernel; VQH_LN_BWD_BLOCKS overrides (A/B runs)
+        static int cap = 0;
+        if (cap == 0) {
+            const char* e = getenv("VQH_LN_BWD_BLOCKS");
+            cap = e ? atoi(e) : 1024;
+            if (cap < 1) cap = 1024;
+        }
+        if (nblk > cap) nblk = cap;
+    }
     VQH_CHECK_ARG((long long)nblk * 2 * H <= workspace_floats, "vqh_layernorm_bwd: workspace too small");
     const bool vec = (H % 4 == 0) && H <= 1024 && ((lddy | ldx | lddx) % 4 == 0) &&
                      (((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
