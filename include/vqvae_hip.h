@@ -77,12 +77,16 @@ int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* problems, float* workspace, l
  * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads);
  * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier; bit 6 = no skinny-shape
  * streaming kernels (everything on the MFMA tile kernel); bit 7 = no 256x128 LDS-DMA kernel (everything that tiles
- * evenly stays on the 128x128 register-staged kernel); bit 8 = vqh_gemm_wgrad_group runs its products one by one */
+ * evenly stays on the 128x128 register-staged kernel); bit 8 = vqh_gemm_wgrad_group runs its products one by one;
+ * bit 9 (512) = the 256x128 tiles run on the native fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the default, which feeds
+ * the bf16 matrix pipes with an EXACT three-way split of every fp32 operand (a = h + m + l, six cross products, fp32
+ * accumulation): same accuracy as the fp32 MFMA against fp64 (csrc/gemm_dma.inc, tools/x3_lab.hip), 1.6-1.7x its speed */
 int vqh_gemm_set_flags(int flags);
 
 /* Live timing of the GEMM main kernels with HIP events on their launch stream (bench.py's roofline figure):
- * begin(), run eager (non-captured) steps, end(out) with out = double[3][4][9][3]: for kernel family (0 = gemm_f32_mfma,
- * the 128x128 register-staged tile; 1 = gemm_f32_dma, the 256x128 LDS-DMA tile; 2 = gemm_f32_dma_group, one entry per launch), operand layout (a_kcontig*2 +
+ * begin(), run eager (non-captured) steps, end(out) with out = double[5][4][9][3]: for kernel family (0 = gemm_f32_mfma,
+ * the 128x128 register-staged tile; 1 = gemm_f32_dma, the 256x128 LDS-DMA tile; 2 = gemm_f32_dma_group, one entry per launch;
+ * 3 = gemm_f32_x3 and 4 = gemm_f32_x3_group, the same tiles on the bf16 pipes), operand layout (a_kcontig*2 +
  * b_kcontig) and kernel template MODE+1 (0 = generic kernel, 1.. = epilogue-specialised): launches, kernel seconds,
  * sum of 2*M*N*K.  The split-K reduce launch is not inside the bracket. */
 int vqh_gemm_profile_begin(void);

@@ -20,6 +20,7 @@
 //                         ds_read_b32 (32 consecutive dwords per half: conflict free).
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include <vector>
 #include <algorithm>
 
@@ -711,7 +712,8 @@ struct ProfRec { int slot; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 constexpr int PROF_MODES = 9;                       // template MODE -1..7 -> column MODE+1
-constexpr int PROF_FAMILIES = 3;                    // 0 = gemm_f32_mfma (128x128 tile), 1 = gemm_f32_dma (256x128 tile), 2 = gemm_f32_dma_group
+constexpr int PROF_FAMILIES = 5;                    // 0 = gemm_f32_mfma (128x128 tile), 1 = gemm_f32_dma (256x128 tile), 2 = gemm_f32_dma_group,
+                                                    // 3 = gemm_f32_x3 (256x128 tile, bf16x3 split operands), 4 = gemm_f32_x3_group
 inline int prof_slot(bool a_kc, bool b_kc, int mode_t, int family = 0) {
     return (family * 4 + (a_kc ? 2 : 0) + (b_kc ? 1 : 0)) * PROF_MODES + mode_t + 1;
 }
@@ -753,11 +755,12 @@ int launch(const GemmArgs& g, int splits, hipStream_t stream) {
     return VQH_OK;
 }
 
-template <bool A_KC, bool B_KC, int MODE = -1>
-int launch_dma(const GemmArgs& g, int splits, hipStream_t stream) {
+template <bool A_KC, bool B_KC, int MODE, bool X3>
+int launch_dma_impl(const GemmArgs& g, int splits, hipStream_t stream) {
     static bool attr_set = false;
+    auto kern = X3 ? &gemm_f32_x3<A_KC, B_KC, MODE> : &gemm_f32_dma<A_KC, B_KC, MODE>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma<A_KC, B_KC, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, dma::LDS_BYTES);
         if (e != hipSuccess) {
             vqh_set_error(hipGetErrorString(e));
@@ -768,7 +771,7 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t stream) {
     dim3 grid((g.M / dma::TBM) * (g.N / dma::TBN), 1, splits);
     ProfRec rec{};
     if (g_prof_on) {
-        rec.slot = prof_slot(A_KC, B_KC, MODE, 1);
+        rec.slot = prof_slot(A_KC, B_KC, MODE, X3 ? 3 : 1);
         rec.flops = 2.0 * g.M * g.N * g.K;
         if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess ||
             hipEventRecord(rec.e0, stream) != hipSuccess) {
@@ -776,7 +779,7 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t stream) {
             return VQH_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL((gemm_f32_dma<A_KC, B_KC, MODE>), grid, dim3(256), dma::LDS_BYTES, stream, g);
+    hipLaunchKernelGGL(kern, grid, dim3(256), dma::LDS_BYTES, stream, g);
     VQH_LAUNCH_CHECK();
     if (g_prof_on) {
         if (hipEventRecord(rec.e1, stream) != hipSuccess) {
@@ -788,10 +791,17 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t stream) {
     return VQH_OK;
 }
 
+// g_gemm_flags bit 512 selects the native fp32 MFMA tile; the default is the bf16x3 split tile (same results to fp32 round-off)
+template <bool A_KC, bool B_KC, int MODE = -1>
+int launch_dma(const GemmArgs& g, int splits, hipStream_t stream) {
+    if (g.flags & 512) return launch_dma_impl<A_KC, B_KC, MODE, false>(g, splits, stream);
+    return launch_dma_impl<A_KC, B_KC, MODE, true>(g, splits, stream);
+}
+
 }  // namespace
 
 // Timing of every GEMM main-kernel launch between begin and end (not under stream capture).  end() synchronises
-// the recorded events and fills out[3][4][9][3]: per (kernel family 0 = gemm_f32_mfma / 1 = gemm_f32_dma / 2 = gemm_f32_dma_group, operand layout
+// the recorded events and fills out[5][4][9][3]: per (kernel family 0 = gemm_f32_mfma / 1 = gemm_f32_dma / 2 = gemm_f32_dma_group / 3 = gemm_f32_x3 / 4 = gemm_f32_x3_group, operand layout
 // a_kc*2+b_kc, template MODE+1) the number of
 // launches, the summed kernel seconds and the summed 2*M*N*K.  The split-K reduce launch is outside the bracket.
 extern "C" int vqh_gemm_profile_begin(void) {
@@ -1142,12 +1152,16 @@ extern "C" int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* pr, float* workspa
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma_group),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, dma::LDS_BYTES);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_x3_group), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        dma::LDS_BYTES);
             if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
             attr_set = true;
         }
+        const bool native = (g_gemm_flags & 512) != 0;
         ProfRec rec{};
         if (g_prof_on) {
-            rec.slot = prof_slot(false, false, EPI_LINEAR, 2);
+            rec.slot = prof_slot(false, false, EPI_LINEAR, native ? 2 : 4);
             rec.flops = flops;
             if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess ||
                 hipEventRecord(rec.e0, stream) != hipSuccess) {
@@ -1155,7 +1169,8 @@ extern "C" int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* pr, float* workspa
                 return VQH_ERR_LAUNCH;
             }
         }
-        hipLaunchKernelGGL(gemm_f32_dma_group, dim3(wg), dim3(256), dma::LDS_BYTES, stream, G);
+        if (native) hipLaunchKernelGGL(gemm_f32_dma_group, dim3(wg), dim3(256), dma::LDS_BYTES, stream, G);
+        else hipLaunchKernelGGL(gemm_f32_x3_group, dim3(wg), dim3(256), dma::LDS_BYTES, stream, G);
         VQH_LAUNCH_CHECK();
         if (g_prof_on) {
             if (hipEventRecord(rec.e1, stream) != hipSuccess) {

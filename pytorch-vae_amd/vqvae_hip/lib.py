@@ -111,22 +111,28 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, mode=EPI_LIN
     _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws)
 
 
+GEMM_PROF_FAMILIES = 5
+GEMM_FLAG_NATIVE_F32 = 512          # vqh_gemm_set_flags bit: large tiles on v_mfma_f32_32x32x2_f32 instead of the bf16x3 split
+
+
 def gemm_profile(fn):
     """Run fn() with the library's per-launch GEMM timing on; returns {(family, a_kc, b_kc, MODE): (launches, seconds, flops)}
     keyed like the kernels' template arguments: family 0 = gemm_f32_mfma<a_kc, b_kc, 32, MODE> (128x128 tile),
-    family 1 = gemm_f32_dma<a_kc, b_kc, MODE> (256x128 tile, LDS-DMA), family 2 = gemm_f32_dma_group (grouped weight gradients)."""
+    family 1 = gemm_f32_dma<a_kc, b_kc, MODE> (256x128 tile, LDS-DMA, native fp32 MFMA), family 2 = gemm_f32_dma_group (grouped
+    weight gradients), families 3 / 4 = gemm_f32_x3<...> / gemm_f32_x3_group: the same tiles on the bf16 matrix pipes (exact 3-way
+    operand split, 6 products; the default)."""
     import ctypes
     lib().vqh_gemm_profile_begin()
     try:
         fn()
         torch.cuda.synchronize()
     finally:
-        out = (ctypes.c_double * (3 * 4 * 9 * 3))()
+        out = (ctypes.c_double * (GEMM_PROF_FAMILIES * 4 * 9 * 3))()
         rc = lib().vqh_gemm_profile_end(ctypes.cast(out, ctypes.c_void_p))
     if rc != 0:
         raise VqhError(f"vqh_gemm_profile_end failed: {lib().vqh_last_error().decode()}")
     res = {}
-    for fam in range(3):
+    for fam in range(GEMM_PROF_FAMILIES):
         for lay in range(4):
             for mc in range(9):
                 o = ((fam * 4 + lay) * 9 + mc) * 3
@@ -158,7 +164,15 @@ def gemm_kernel_name(key):
         return "gemm_f32_mfma<%s, %s, 32, %d>" % (tf(a_kc), tf(b_kc), mode)
     if fam == 2:
         return "gemm_f32_dma_group"
+    if fam == 4:
+        return "gemm_f32_x3_group"
+    if fam == 3:
+        return "gemm_f32_x3<%s, %s, %d>" % (tf(a_kc), tf(b_kc), mode)
     return "gemm_f32_dma<%s, %s, %d>" % (tf(a_kc), tf(b_kc), mode)
+
+
+def gemm_kernel_is_x3(key):
+    return key[0] in (3, 4)
 
 
 class WgradT(C.Structure):
