@@ -381,19 +381,19 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_tile(const float* __restrict__ 
                 constexpr int u = m / 7, ph = m % 7;
                 using U = std::integral_constant<int, u>;
                 // slot plan of a unit: 6 VALU | 6 VALU | W(h) + 2 | W(m) + 2 | load | 6 VALU | W(l)
-                if constexpr (!(ABL & 1)) {
+                if constexpr (!(ABL & 1) && !((ABL & 32) && u >= NUA)) {
                     if constexpr (ph == 0) su.template step<0>(st[u]);
                     if constexpr (ph == 1) su.template step<1>(st[u]);
                     if constexpr (ph == 2) su.template step<2>(st[u]);
                     if constexpr (ph == 3) su.template step<3>(st[u]);
                     if constexpr (ph == 5) su.template step<4>(st[u]);
                 }
-                if constexpr (!(ABL & 2)) {
+                if constexpr (!(ABL & 2) && !((ABL & 32) && u >= NUA)) {
                     if constexpr (ph == 2) write_unit(U{}, I0{}, ws);
                     if constexpr (ph == 3) write_unit(U{}, I1{}, ws);
                     if constexpr (ph == 6) write_unit(U{}, I2{}, ws);
                 }
-                if constexpr (ph == 4 && !(ABL & 4)) load_unit(U{}, kt_ld);
+                if constexpr (ph == 4 && !(ABL & 4) && !((ABL & 32) && u >= NUA)) load_unit(U{}, kt_ld);
             }
             if constexpr (m == BAR - 1 && !(ABL & 16)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -504,6 +504,7 @@ static int tile_main(int argc, char** argv) {
         {"NT 8w stamps -wr", run_x3<true, true, true, 2, 8>, run_ref<true, true>, true},
         {"NT 8w stamps -valu", run_x3<true, true, true, 1, 8>, run_ref<true, true>, true},
         {"NT 8w stamps mfma only", run_x3<true, true, true, 31, 8>, run_ref<true, true>, true},
+        {"NT stamps -Bunits", run_x3<true, true, true, 32>, run_ref<true, true>, true},
         {"NT stamps -valu", run_x3<true, true, true, 1>, run_ref<true, true>, true},
         {"NT stamps -valu -wr", run_x3<true, true, true, 3>, run_ref<true, true>, true},
         {"NT stamps -valu -wr -ld", run_x3<true, true, true, 7>, run_ref<true, true>, true},
@@ -521,6 +522,10 @@ static int tile_main(int argc, char** argv) {
         {"native TN (shipped)", run_ref<false, false>, run_ref<false, false>, false},
         {"x3 TN", run_x3<false, false, false>, run_ref<false, false>, false},
         {"x3 TN stamps", run_x3<false, false, true>, run_ref<false, false>, true},
+        {"TN stamps -rd", run_x3<false, false, true, 8>, run_ref<false, false>, true},
+        {"TN stamps -wr", run_x3<false, false, true, 2>, run_ref<false, false>, true},
+        {"TN stamps -valu", run_x3<false, false, true, 1>, run_ref<false, false>, true},
+        {"TN stamps -ld", run_x3<false, false, true, 4>, run_ref<false, false>, true},
         {"x3 TN 8w", run_x3<false, false, false, 0, 8>, run_ref<false, false>, false},
         {"x3 TN 8w stamps", run_x3<false, false, true, 0, 8>, run_ref<false, false>, true},
     };
