@@ -78,6 +78,7 @@ int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* problems, float* workspace, l
  * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier; bit 6 = no skinny-shape
  * streaming kernels (everything on the MFMA tile kernel); bit 7 = no 256x128 LDS-DMA kernel (everything that tiles
  * evenly stays on the 128x128 register-staged kernel); bit 8 = vqh_gemm_wgrad_group runs its products one by one;
+ * bit 10 (1024) = no XCD-contiguous order in the grouped kernels, bit 11 (2048) = x3 tiles stage linear outputs through LDS (A/B);
  * bit 9 (512) = the 256x128 tiles run on the native fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of the default, which feeds
  * the bf16 matrix pipes with an EXACT three-way split of every fp32 operand (a = h + m + l, six cross products, fp32
  * accumulation): same accuracy as the fp32 MFMA against fp64 (csrc/gemm_dma.inc, tools/x3_lab.hip), 1.6-1.7x its speed */
