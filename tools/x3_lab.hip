@@ -1,8 +1,11 @@
-// x3 lab (diagnostic, not product): accuracy of an fp32 GEMM computed on the bf16 matrix pipes from EXACT three-way operand
-// splits (a = h + m + l, each a bf16; six of the nine cross products, fp32 accumulation in the MFMA), against fp64 on the
-// host and against the native fp32 MFMA (v_mfma_f32_32x32x2_f32) on the same data.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/x3_lab.hip -o tools/_build/x3_lab
-//   tools/_build/x3_lab [M N K]
+// x3 lab (diagnostic, not product): an fp32 GEMM computed on the bf16 matrix pipes from EXACT three-way operand splits
+// (a = h + m + l, each a bf16; six of the nine cross products, fp32 accumulation in the MFMA).
+//   tools/build_lab.sh                      (hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/x3_lab.hip -o tools/_build/x3_lab -ldl)
+//   tools/_build/x3_lab [M N K]             accuracy against fp64 on the host and against the native fp32 MFMA
+//                                           (v_mfma_f32_32x32x2_f32), one wave per 32x32 block: 3 / 6 / 9 products, truncating split
+//   tools/_build/x3_lab tile [M N K]...     the 256x128x32 tile kernel (the lab form of csrc/gemm_dma.inc's x3 loop) in the three
+//                                           operand layouts, 4 and 8 waves, with s_memtime stamps and ablations (-valu, -wr, -ld,
+//                                           -rd, -bar, -Bunits, split reads), against the shipped vqh_gemm (run from the repo root)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -317,6 +320,20 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_tile(const float* __restrict__ 
             return u32x4{l2[0], l2[1], h2[0], h2[1]};
         }
     };
+    // row-contiguous operands: one HALF of a fragment (a single ds_read_b64_tr_b16) so that the two reads of a fragment can sit
+    // in consecutive MFMA slots
+    auto read_A_half = [&](auto pl_c, auto i_c, auto g_c, auto t_c, const unsigned char* sb, u32x4& f) {
+        constexpr int pl = decltype(pl_c)::value, i = decltype(i_c)::value, g = decltype(g_c)::value, t = decltype(t_c)::value;
+        const unsigned a0 = (unsigned)(uintptr_t)(sb + pl * A_PLANE + (16 * g + 4 * t) * 512 + rA[i]);
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0));
+        f[2 * t] = v[0]; f[2 * t + 1] = v[1];
+    };
+    auto read_B_half = [&](auto pl_c, auto j_c, auto g_c, auto t_c, const unsigned char* sb, u32x4& f) {
+        constexpr int pl = decltype(pl_c)::value, j = decltype(j_c)::value, g = decltype(g_c)::value, t = decltype(t_c)::value;
+        const unsigned a0 = (unsigned)(uintptr_t)(sb + B_OFF + pl * B_PLANE + (16 * g + 4 * t) * 256 + rB[j]);
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)a0));
+        f[2 * t] = v[0]; f[2 * t + 1] = v[1];
+    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
@@ -366,13 +383,27 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_tile(const float* __restrict__ 
                         for (int ii = 0; ii < MI; ++ii) asm volatile("" : "+v"(fA[pp][ii]));
                 }
             } else {
-#define RD_AM0(ii) if constexpr (ii < MI && m == ii * S) fA[1][ii] = read_A(I1{}, std::integral_constant<int, ii>{}, I0{}, rs);
-#define RD_AL0(ii) if constexpr (ii < MI && m == (MI + ii) * S) fA[2][ii] = read_A(I2{}, std::integral_constant<int, ii>{}, I0{}, rs);
-#define RD_B1(xx) if constexpr (m == (2 * MI + xx) * S) fB[1][xx / 2][xx % 2] = read_B(std::integral_constant<int, xx / 2>{}, std::integral_constant<int, xx % 2>{}, I1{}, rs);
-#define RD_AH1(ii) if constexpr (ii < MI && m == 3 * NB + (MI == 4 ? 4 + 4 * ii : 1 + 2 * ii)) fA[0][ii] = read_A(I0{}, std::integral_constant<int, ii>{}, I1{}, rs);
-#define RD_AM1(ii) if constexpr (ii < MI && m == G + ii * S) fA[1][ii] = read_A(I1{}, std::integral_constant<int, ii>{}, I1{}, rs);
-#define RD_AL1(ii) if constexpr (ii < MI && m == G + (MI + ii) * S) fA[2][ii] = read_A(I2{}, std::integral_constant<int, ii>{}, I1{}, rs);
-#define RD_AHN(ii) if constexpr (ii < MI && m == (MI == 4 ? BAR + ii : BAR)) fA[0][ii] = read_A(I0{}, std::integral_constant<int, ii>{}, I0{}, ws);
+#define RDA(PL, II, GG, STG, DST, SLOT)                                                                                         \
+    if constexpr (!A_KC && (ABL & 64)) {                                                                                        \
+        if constexpr (m == (SLOT)) read_A_half(std::integral_constant<int, PL>{}, std::integral_constant<int, II>{}, std::integral_constant<int, GG>{}, I0{}, STG, DST); \
+        if constexpr (m == (SLOT) + 1) read_A_half(std::integral_constant<int, PL>{}, std::integral_constant<int, II>{}, std::integral_constant<int, GG>{}, I1{}, STG, DST); \
+    } else {                                                                                                                    \
+        if constexpr (m == (SLOT)) DST = read_A(std::integral_constant<int, PL>{}, std::integral_constant<int, II>{}, std::integral_constant<int, GG>{}, STG); \
+    }
+#define RDB(PL, JJ, GG, STG, DST, SLOT)                                                                                         \
+    if constexpr (!B_KC && (ABL & 64)) {                                                                                        \
+        if constexpr (m == (SLOT)) read_B_half(std::integral_constant<int, PL>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, GG>{}, I0{}, STG, DST); \
+        if constexpr (m == (SLOT) + 1) read_B_half(std::integral_constant<int, PL>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, GG>{}, I1{}, STG, DST); \
+    } else {                                                                                                                    \
+        if constexpr (m == (SLOT)) DST = read_B(std::integral_constant<int, PL>{}, std::integral_constant<int, JJ>{}, std::integral_constant<int, GG>{}, STG); \
+    }
+#define RD_AM0(ii) if constexpr (ii < MI) { RDA(1, ii, 0, rs, fA[1][ii], ii * S) }
+#define RD_AL0(ii) if constexpr (ii < MI) { RDA(2, ii, 0, rs, fA[2][ii], (MI + ii) * S) }
+#define RD_B1(xx) { RDB(xx / 2, xx % 2, 1, rs, fB[1][xx / 2][xx % 2], (2 * MI + xx) * S) }
+#define RD_AH1(ii) if constexpr (ii < MI) { RDA(0, ii, 1, rs, fA[0][ii], 3 * NB + (MI == 4 ? 4 + 4 * ii : 1 + 2 * ii)) }
+#define RD_AM1(ii) if constexpr (ii < MI) { RDA(1, ii, 1, rs, fA[1][ii], G + ii * S) }
+#define RD_AL1(ii) if constexpr (ii < MI) { RDA(2, ii, 1, rs, fA[2][ii], G + (MI + ii) * S) }
+#define RD_AHN(ii) if constexpr (ii < MI) { if constexpr (m == (MI == 4 ? BAR + ii : BAR)) fA[0][ii] = read_A(I0{}, std::integral_constant<int, ii>{}, I0{}, ws); }
 #define RD_BN(xx) if constexpr (m == (MI == 4 ? BAR + MI + xx : BAR + 1 + xx / 2)) fB[0][xx / 2][xx % 2] = read_B(std::integral_constant<int, xx / 2>{}, std::integral_constant<int, xx % 2>{}, I0{}, ws);
                 X3_FOR_I(RD_AM0) X3_FOR_I(RD_AL0) X3_FOR_X(RD_B1) X3_FOR_I(RD_AH1) X3_FOR_I(RD_AM1) X3_FOR_I(RD_AL1) X3_FOR_I(RD_AHN) X3_FOR_X(RD_BN)
             }
@@ -522,6 +553,8 @@ static int tile_main(int argc, char** argv) {
         {"native TN (shipped)", run_ref<false, false>, run_ref<false, false>, false},
         {"x3 TN", run_x3<false, false, false>, run_ref<false, false>, false},
         {"x3 TN stamps", run_x3<false, false, true>, run_ref<false, false>, true},
+        {"TN stamps split reads", run_x3<false, false, true, 64>, run_ref<false, false>, true},
+        {"x3 TN split reads", run_x3<false, false, false, 64>, run_ref<false, false>, false},
         {"TN stamps -rd", run_x3<false, false, true, 8>, run_ref<false, false>, true},
         {"TN stamps -wr", run_x3<false, false, true, 2>, run_ref<false, false>, true},
         {"TN stamps -valu", run_x3<false, false, true, 1>, run_ref<false, false>, true},
@@ -568,7 +601,7 @@ static int tile_main(int argc, char** argv) {
                 worst = std::max(worst, d);
                 scale = std::max(scale, (double)fabsf(hR[i]));
             }
-            if (strstr(vars[v].name, " -") || strstr(vars[v].name, "only")) continue;
+            if (strstr(vars[v].name, " -") || strstr(vars[v].name, "only")) continue;   // ablations compute garbage
             printf("   %-24s max|diff vs native| %.3e (scale %.3e)%s\n", vars[v].name, worst, scale,
                    (!(worst <= 2e-5 * scale) || bad) ? "   !! MISMATCH" : "");
         }
