@@ -270,7 +270,8 @@ def main():
             dom = max(prof, key=lambda k: prof[k][1])            # the instantiation with the largest summed time
             n, t, f = prof[dom]
             kname = L.gemm_kernel_name(dom)
-            traffic, traffic_src = pmc_traffic(kname)
+            # the committed counter passes were taken on C2: per-launch bytes of another workload are not known
+            traffic, traffic_src = pmc_traffic(kname) if args.workload == "c2" and not args.batch and not args.seq else (None, None)
             per_kernel = {L.gemm_kernel_name(k): {"launches_per_step": v[0] // 2, "avg_launch_us": round(v[1] / v[0] * 1e6, 2),
                                                   "achieved": round(v[2] / v[1] / 1e12, 2)}
                           for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
