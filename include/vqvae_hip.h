@@ -163,7 +163,8 @@ int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long*
  * workspace_floats >= 3T + 4K + 2R + 3*nsplit*R + R/4 + 8 with T = smallest power of two >= 2K (>= 64), nsplit <= K/256 + 1 */
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
                    int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);
-/* diagnostic: bit 0 = always use the per-wave global-gather nearest kernel (round-1 form); returns the previous flags */
+/* diagnostic: bit 0 = always use the per-wave global-gather nearest kernel (round-1 form); bit 1 = score with the fp32 MFMA
+ * instead of the bf16 pipes on exactly split operands (D = 64 / 128 / 256; same indices); returns the previous flags */
 int vqh_vq_set_flags(int flags);
 /* live timing of the nearest-neighbour main kernel with HIP events on its launch stream (bench.py --vq-only):
  * begin(), eager calls, end(out) with out = double[3] = {launches, kernel seconds, sum of 2*R*K*D} */

@@ -293,6 +293,202 @@ __global__ __launch_bounds__(256, 2) void vq_nearest_lds_kernel(const float* __r
     }
 }
 
+// ---- split-operand form (D = 16 * NT16 in {64, 128, 256}) ------------------------------------------------------------------
+// The scores E . Z^T on the bf16 matrix pipes from EXACT three-way splits of both operands (the scheme of gemm_dma.inc's
+// x3 tiles: a = h + m + l, six products, fp32 accumulation; as close to fp64 as the fp32 MFMA).  Here the split costs
+// nothing inside the loop: the codebook is split ONCE per call by vq_split_codebook_kernel into rows of [h | m | l | pad]
+// (6 D + 16 bytes: the pad makes the 32 rows of a fragment read hit 16 different 16-byte bank slots), so a code tile goes
+// to LDS as a plain copy, and a wave splits its 32 rows of Z once into registers (3 D / 4 VGPRs per lane).  Per 32-code
+// block: D / 16 * 6 MFMAs of 32 cycles instead of D / 2 of 64.  Top-2 tracking, tie rules, the noise band and the fp64
+// re-evaluation of ambiguous rows are those of the fp32 kernels (the band is 30x the error of either arithmetic).
+typedef unsigned vq_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 vq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vq_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void vq_split_pair(float a0, float a1, unsigned& hp, unsigned& mp, unsigned& lp) {
+    const vq_bf16x2 h2 = {(__bf16)a0, (__bf16)a1};
+    const float r0 = a0 - (float)h2[0], r1 = a1 - (float)h2[1];
+    const vq_bf16x2 m2 = {(__bf16)r0, (__bf16)r1};
+    const float s0 = r0 - (float)m2[0], s1 = r1 - (float)m2[1];
+    const vq_bf16x2 l2 = {(__bf16)s0, (__bf16)s1};
+    hp = __builtin_bit_cast(unsigned, h2);
+    mp = __builtin_bit_cast(unsigned, m2);
+    lp = __builtin_bit_cast(unsigned, l2);
+}
+
+// Ex[k] = [h plane: D bf16 | m plane | l plane | 16 bytes pad]; one thread per pair of elements
+__global__ void vq_split_codebook_kernel(const float* __restrict__ E, int lde, int K, int D, unsigned char* __restrict__ Ex) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = D / 2;
+    if (i >= (long long)K * half) return;
+    const int k = (int)(i / half), c = (int)(i % half) * 2;
+    const float a0 = E[(size_t)k * lde + c], a1 = E[(size_t)k * lde + c + 1];
+    unsigned hp, mp, lp;
+    vq_split_pair(a0, a1, hp, mp, lp);
+    unsigned char* row = Ex + (size_t)k * (6 * D + 16);
+    *reinterpret_cast<unsigned*>(row + 2 * c) = hp;
+    *reinterpret_cast<unsigned*>(row + 2 * D + 2 * c) = mp;
+    *reinterpret_cast<unsigned*>(row + 4 * D + 2 * c) = lp;
+}
+
+template <int NT16>
+__global__ __launch_bounds__(256, (NT16 >= 16) ? 1 : 2) void vq_nearest_x3_kernel(const float* __restrict__ Z, int ldz,
+                                                                                 const unsigned char* __restrict__ Ex,
+                                                                                 const float* __restrict__ enorm,
+                                                                                 const int* __restrict__ canon,
+                                                                                 float* __restrict__ pbest,
+                                                                                 float* __restrict__ psecond,
+                                                                                 int* __restrict__ pidx, int R, int K, int kchunk) {
+    constexpr int D = 16 * NT16, ROWB = 6 * D + 16;
+    constexpr int CT = (NT16 >= 16) ? 32 : 64;                // codes per LDS tile
+    constexpr int TILE_B = CT * ROWB;                         // bytes per code tile
+    constexpr int CHUNKS = TILE_B / 16;                       // 16-byte chunks per tile
+    constexpr int LPT = (CHUNKS + 255) / 256;                 // chunk loads per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    auto tileb = [&](int b) { return xsm + b * TILE_B; };
+    auto nrm = [&](int b) { return reinterpret_cast<float*>(xsm + 2 * TILE_B) + b * CT; };
+    auto can = [&](int b) { return reinterpret_cast<int*>(xsm + 2 * TILE_B + 2 * CT * 4) + b * CT; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 128 + wave * 32 + l31;
+    const bool rok = row < R;
+    const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+
+    // this lane's share of its row of Z as three bf16 planes: group g holds k = 16 g + 8 h .. + 7
+    vq_u32x4 zh[NT16], zm[NT16], zl[NT16];
+#pragma unroll
+    for (int g = 0; g < NT16; ++g) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (rok) {
+            a = *reinterpret_cast<const f32x4*>(Z + (size_t)row * ldz + 16 * g + 8 * h);
+            b = *reinterpret_cast<const f32x4*>(Z + (size_t)row * ldz + 16 * g + 8 * h + 4);
+        }
+        unsigned ph[4], pm[4], pl[4];
+        vq_split_pair(a[0], a[1], ph[0], pm[0], pl[0]);
+        vq_split_pair(a[2], a[3], ph[1], pm[1], pl[1]);
+        vq_split_pair(b[0], b[1], ph[2], pm[2], pl[2]);
+        vq_split_pair(b[2], b[3], ph[3], pm[3], pl[3]);
+        zh[g] = vq_u32x4{ph[0], ph[1], ph[2], ph[3]};
+        zm[g] = vq_u32x4{pm[0], pm[1], pm[2], pm[3]};
+        zl[g] = vq_u32x4{pl[0], pl[1], pl[2], pl[3]};
+    }
+    vq_u32x4 stg[LPT];
+    float stg_n = 0.f;
+    int stg_c = 0;
+    auto load_tile = [&](int c0) {
+        const int ncodes = min(CT, kend - c0);                // codes of this tile that exist (rows beyond stay stale: never scored)
+        const unsigned char* src = Ex + (size_t)c0 * ROWB;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int ch = tid + 256 * i;
+            stg[i] = vq_u32x4{0u, 0u, 0u, 0u};
+            if (ch < CHUNKS && ch * 16 < ncodes * ROWB) stg[i] = *reinterpret_cast<const vq_u32x4*>(src + (size_t)ch * 16);
+        }
+        if (tid < CT) {
+            const int code = c0 + tid;
+            stg_n = (code < kend) ? enorm[code] : 0.f;
+            stg_c = (code < kend) ? canon[code] : -1;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int ch = tid + 256 * i;
+            if (ch < CHUNKS) *reinterpret_cast<vq_u32x4*>(tileb(buf) + (size_t)ch * 16) = stg[i];
+        }
+        if (tid < CT) { nrm(buf)[tid] = stg_n; can(buf)[tid] = stg_c; }
+    };
+
+    float best = INFINITY, second = INFINITY;
+    int bidx = 0x7fffffff, bcan = -1;
+    load_tile(kbeg);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = kbeg; c0 < kend; c0 += CT) {
+        const bool more = c0 + CT < kend;
+        if (more) load_tile(c0 + CT);
+        const unsigned char* tb = tileb(buf);
+        const float* nb = nrm(buf);
+        const int* cb = can(buf);
+#pragma unroll
+        for (int blk = 0; blk < CT / 32; ++blk) {
+            if (c0 + blk * 32 >= kend) break;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const unsigned char* ep = tb + (size_t)(blk * 32 + l31) * ROWB + 16 * h;
+            // the three plane fragments of group g + 1 are requested between the six MFMAs of group g (at D = 256 the
+            // 192 registers of Z planes leave the compiler no room to keep both sets apart: it issues the reads late and
+            // half of the LDS latency stays exposed; Z planes in AGPRs through inline-asm MFMAs were tried and dropped)
+            vq_u32x4 ef[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ef[0][pl] = *reinterpret_cast<const vq_u32x4*>(ep + pl * 2 * D);
+#pragma unroll
+            for (int g = 0; g < NT16; ++g) {
+                if (g + 1 < NT16) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) ef[(g + 1) & 1][pl] = *reinterpret_cast<const vq_u32x4*>(ep + pl * 2 * D + 32 * (g + 1));
+                }
+                const vq_bf16x8 eh = __builtin_bit_cast(vq_bf16x8, ef[g & 1][0]), em = __builtin_bit_cast(vq_bf16x8, ef[g & 1][1]),
+                                el = __builtin_bit_cast(vq_bf16x8, ef[g & 1][2]);
+                const vq_bf16x8 bh = __builtin_bit_cast(vq_bf16x8, zh[g]), bm = __builtin_bit_cast(vq_bf16x8, zm[g]),
+                                bl = __builtin_bit_cast(vq_bf16x8, zl[g]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(em, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(em, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, bh, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < NT16; ++g)
+#pragma unroll
+                for (int m6 = 0; m6 < 6; ++m6) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m6 < 3 && g + 1 < NT16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            // acc[r] = dot(E[c0 + 32 blk + kmap(r,h)], Z[row])
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = blk * 32 + kmap(r, h);
+                const int code = c0 + cl;
+                if (code < kend) {
+                    const float d = nb[cl] - 2.f * acc[r];
+                    if (d < best) {
+                        second = best;
+                        best = d;
+                        bidx = code;
+                        bcan = cb[cl];
+                    } else if (d < second) {
+                        if (!(d == best && cb[cl] == bcan)) second = d;    // an exact duplicate of the best is not a rival
+                    }
+                }
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // combine the two lane halves (same row, disjoint code subsets)
+    const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
+    const int oi = __shfl_xor(bidx, 32, 64), oc = __shfl_xor(bcan, 32, 64);
+    const bool dup = (ob == best) && (oc == bcan);
+    float fb, fs;
+    int fi;
+    if (ob < best || (ob == best && oi < bidx)) {
+        fb = ob; fi = oi; fs = dup ? fminf(second, os) : fminf(best, os);
+    } else {
+        fb = best; fi = bidx; fs = dup ? fminf(second, os) : fminf(ob, second);
+    }
+    if (rok && h == 0) {
+        const size_t o = (size_t)blockIdx.y * R + row;
+        pbest[o] = fb;
+        psecond[o] = fs;
+        pidx[o] = fi;
+    }
+}
+
 // merge the per-range partials (ascending code ranges), write the index and flag rows whose top-2 gap is inside the
 // fp32 noise band; bestval keeps the winning score for the refinement's pre-filter.
 __global__ void vq_combine_kernel(const float* __restrict__ pbest, const float* __restrict__ psecond,
@@ -592,7 +788,7 @@ namespace {
 struct VqProfRec { double flops; hipEvent_t e0, e1; };
 bool g_vq_prof_on = false;
 std::vector<VqProfRec> g_vq_prof;
-int g_vq_flags = 0;             // bit 0: force the per-wave global-gather kernel (round-1 form), for A/B runs and tests
+int g_vq_flags = 0;             // bit 0: force the per-wave global-gather kernel (round-1 form); bit 1: fp32 MFMA instead of the split-operand kernel
 }  // namespace
 extern "C" int vqh_vq_set_flags(int flags) { const int old = g_vq_flags; g_vq_flags = flags; return old; }
 extern "C" int vqh_vq_profile_begin(void) {
@@ -634,6 +830,9 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     // LDS-staged kernel: 128 rows per workgroup; D/8 in {1,2,4,8,16,32}
     const int nt8 = D / 8;
     const bool lds_form = !(g_vq_flags & 1) && D <= 256 && (nt8 & (nt8 - 1)) == 0;
+    // split-operand (bf16 pipes) form for D in {64, 128, 256}; bit 1 of the flags keeps the fp32 MFMA kernel (A/B runs, tests)
+    const bool x3_form = lds_form && !(g_vq_flags & 2) && (D == 64 || D == 128 || D == 256);
+    const long long ex_floats = x3_form ? ((long long)K * (6 * D + 16) + 3) / 4 : 0;
     const int rows_per_block = lds_form ? 128 : 32;
     const int row_blocks = (R + rows_per_block - 1) / rows_per_block;
     const int target = lds_form ? 512 : 2048;    // workgroups wanted (2 x 256 CUs / ~2048 single waves)
@@ -648,7 +847,7 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     nsplit = (K + kchunk - 1) / kchunk;
     int T = 64;
     while (T < 2 * K) T <<= 1;
-    const long long need = 3LL * T + 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8;
+    const long long need = 3LL * T + 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8 + ex_floats + 4;
     VQH_CHECK_ARG(need <= workspace_floats, "vqh_vq_nearest: workspace too small");
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);       // 2T floats, 8-byte aligned
     int* minidx = reinterpret_cast<int*>(workspace + 2 * (size_t)T);
@@ -661,6 +860,13 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     float* psecond = pbest + (size_t)nsplit * R;
     int* pidx = reinterpret_cast<int*>(psecond + (size_t)nsplit * R);
     unsigned char* amb = reinterpret_cast<unsigned char*>(pidx + (size_t)nsplit * R);
+    // pre-split codebook rows, 16-byte aligned, behind the flag bytes
+    unsigned char* Ex = reinterpret_cast<unsigned char*>(
+        (reinterpret_cast<uintptr_t>(amb + (size_t)((R + 3) / 4) * 4) + 15) & ~(uintptr_t)15);
+    if (x3_form) {
+        const long long pairs = (long long)K * (D / 2);
+        hipLaunchKernelGGL(vq_split_codebook_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, E, lde, K, D, Ex);
+    }
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, enorm, 1.f);
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, R, D, znorm, 1.f);
     hipLaunchKernelGGL(code_hash_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, E, lde, K, D, hash);
@@ -676,7 +882,25 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
             return VQH_ERR_LAUNCH;
         }
     }
-    if (lds_form) {
+    if (x3_form) {
+        const int nt16 = D / 16;
+        const int ct = (nt16 >= 16) ? 32 : 64;
+        const size_t smem = (size_t)2 * ct * (6 * D + 16) + (size_t)4 * ct * sizeof(float);
+#define VQ_X3(N)                                                                                                         \
+    case N: {                                                                                                            \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_nearest_x3_kernel<N>),                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }                         \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL(vq_nearest_x3_kernel<N>, dim3(row_blocks, nsplit), dim3(256), smem, stream, Z, ldz, Ex, enorm, \
+                           canon, pbest, psecond, pidx, R, K, kchunk);                                                   \
+    } break
+        switch (nt16) { VQ_X3(4); VQ_X3(8); VQ_X3(16); default: break; }
+#undef VQ_X3
+    } else if (lds_form) {
         const int ct = (nt8 >= 32) ? 32 : 64;
         const size_t smem = (size_t)(2 * ct * (D + 4) + 4 * ct) * sizeof(float);
 #define VQ_LDS(N)                                                                                                        \

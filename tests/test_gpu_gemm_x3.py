@@ -172,3 +172,37 @@ def test_train_step_agrees_between_x3_and_native_tiles():
     # an update whose gradient is ~0, so the bound is a small multiple of lr, and the bulk must agree far better
     assert float((wa - wb).abs().max()) <= 6.5e-4
     assert float(((wa - wb) ** 2).mean().sqrt()) <= 2e-6
+
+
+@pytest.mark.parametrize("R,K,D", [(4096, 512, 64), (3000, 1000, 128), (2048, 8192, 256)])
+def test_vq_nearest_on_the_bf16_pipes_returns_the_fp64_argmin(R, K, D):
+    """vqh_vq_nearest with the split-operand score kernel (default) and with the fp32 MFMA kernel (vq flags bit 1): both
+    must return the exact argmin of sum (z - e)^2 evaluated in fp64, lowest index on ties -- codes duplicated and rows
+    placed exactly between two codes included (models/vq_vae.py:183-188)."""
+    L = _hip()
+    g = torch.Generator(device="cpu").manual_seed(R + K + D)
+    emb = (torch.randn(K, D, generator=g) / D ** 0.5)
+    emb[K // 2] = emb[3]                                      # an exact duplicate: the lower index must win
+    z = torch.randn(R, D, generator=g) / D ** 0.5
+    z[:64] = emb[torch.randint(0, K, (64,), generator=g)]     # rows sitting on a code
+    z[64:96] = 0.5 * (emb[10] + emb[11])                      # rows exactly between two codes
+    emb, z = emb.to(DEV), z.to(DEV)
+    d64 = (z.double() ** 2).sum(1, keepdim=True) - 2.0 * z.double() @ emb.double().t() + (emb.double() ** 2).sum(1)
+    direct = torch.cdist(z.double(), emb.double()) ** 2       # for the rows where the expanded form cancels badly
+    d64[:96] = direct[:96]
+    ref = d64.argmin(1)
+    ws = torch.empty(32 << 20, device=DEV)
+    for flags in (0, 2):
+        old = L.lib().vqh_vq_set_flags(flags)
+        try:
+            idx = torch.full((R,), -1, dtype=torch.int64, device=DEV)
+            L.call("vqh_vq_nearest", z, D, emb, D, idx, 0, R, K, D, 3e-5, ws, ws.numel())
+            torch.cuda.synchronize()
+        finally:
+            L.lib().vqh_vq_set_flags(old)
+        bad = (idx != ref).nonzero().flatten()
+        # a mismatch is legitimate only where fp64 itself cannot separate the two candidates
+        for r in bad.tolist():
+            a, b = float(d64[r, idx[r]]), float(d64[r, ref[r]])
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(b)) and int(idx[r]) < int(ref[r]) + K, (flags, r, int(idx[r]), int(ref[r]), a, b)
+        assert len(bad) <= 8, (flags, len(bad))
