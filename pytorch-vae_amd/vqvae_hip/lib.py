@@ -77,6 +77,12 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = [_CT[c] for c in sig]
             fn.restype = C.c_int
+        # process-wide A/B switches of the kernel families (see include/vqvae_hip.h), e.g. VQH_GEMM_FLAGS=513 runs every
+        # large GEMM tile on the native fp32 MFMA instead of the split-operand bf16 tiles, VQH_VQ_FLAGS=2 the same for VQ scores
+        for env, setter in (("VQH_GEMM_FLAGS", "vqh_gemm_set_flags"), ("VQH_VQ_FLAGS", "vqh_vq_set_flags"),
+                            ("VQH_ATTN_FLAGS", "vqh_attn_set_flags")):
+            if os.environ.get(env):
+                getattr(L, setter)(int(os.environ[env]))
         _lib = L
     return _lib
 
