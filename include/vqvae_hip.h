@@ -74,7 +74,8 @@ typedef struct vqh_wgrad_t {
 int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* problems, float* workspace, long long workspace_floats, vqh_stream_t stream);
 
 /* tuning knobs of vqh_gemm (returns the previous value): bit0 = XCD-aware tile order (default on);
- * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads);
+ * bits 1,2 are timing-only diagnostics that produce WRONG results (skip stores / skip loads): honoured only by a library
+ * built with -DVQH_DIAG (labs), masked off by the product build;
  * bit 4 = no epilogue-operand prefetch; bit 5 = no fragment pipelining across the K-step barrier; bit 6 = no skinny-shape
  * streaming kernels (everything on the MFMA tile kernel); bit 7 = no 256x128 LDS-DMA kernel (everything that tiles
  * evenly stays on the 128x128 register-staged kernel); bit 8 = vqh_gemm_wgrad_group runs its products one by one;

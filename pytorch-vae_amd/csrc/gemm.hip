@@ -835,7 +835,12 @@ extern "C" int vqh_reduce_slabs(const float* slabs, int S, long long stride, lon
                                 hipStream_t stream);      // rowwise.hip
 
 static int g_gemm_flags = 1;
-extern "C" int vqh_gemm_set_flags(int flags) { const int old = g_gemm_flags; g_gemm_flags = flags; return old; }
+extern "C" int vqh_gemm_set_flags(int flags) {
+#ifndef VQH_DIAG
+    flags &= ~(2 | 4);      // the timing-only bits that skip stores / loads exist in -DVQH_DIAG lab builds only
+#endif
+    const int old = g_gemm_flags; g_gemm_flags = flags; return old;
+}
 
 // C-ABI: see include/vqvae_hip.h for the contract.
 static int gemm_impl(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B,

@@ -171,14 +171,23 @@ class VectorQuantizerEMA(nn.Module):
             raise _L.VqhError("quantizer is not attached to a VQVAE engine")
         B, M, D = z_e.shape
         eng = self._owner()._engine()
+        # a stand-alone call between the model's forward / loss_function / backward must not disturb them: it runs in its
+        # own arena and puts the engine's arena, mode flags and pending-refresh state back afterwards
+        prev_key, prev = eng.arena.key, (eng.train, eng.defer_ema, eng._pending_ema)
         eng.train = self.training
         eng.defer_ema = False
         eng.use_arena(("vq", int(B), int(M)))
-        with torch.no_grad():
-            valid = None if mask is None else mask.to(device=z_e.device, dtype=torch.bool).reshape(B * M)
-            z_st, z_q, idx, stats = eng.quantize(z_e.reshape(B * M, D).contiguous(), B, do_ema_update, row_valid=valid)
-        idx_out = idx.view(B, M).clone() if self.num_quantizers == 1 else idx.clone()
-        return z_st.view(B, M, D).clone(), z_q.view(B, M, D).clone(), idx_out, stats.clone()
+        try:
+            with torch.no_grad():
+                valid = None if mask is None else mask.to(device=z_e.device, dtype=torch.bool).reshape(B * M)
+                z_st, z_q, idx, stats = eng.quantize(z_e.reshape(B * M, D).contiguous(), B, do_ema_update, row_valid=valid)
+            idx_out = idx.view(B, M).clone() if self.num_quantizers == 1 else idx.clone()
+            out = z_st.view(B, M, D).clone(), z_q.view(B, M, D).clone(), idx_out, stats.clone()
+        finally:
+            eng.train, eng.defer_ema, eng._pending_ema = prev
+            if prev_key in eng.arenas:
+                eng.use_arena(prev_key)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -453,17 +462,15 @@ class VQVAE(nn.Module):
         vector (order = vqvae_hip.engine.METRIC_KEYS).  Steady state is a hipGraph replay."""
         eng = self._engine()
         x, mask = self._prep(x, mask)
-        dev = self.head_xyz.weight.device
         eng.betas = tuple(betas)
-        return eng.train_step(x.to(dev, non_blocking=True), mask.to(dev, non_blocking=True) if mask is not None else None,
-                              weights, lr, weight_decay, clip, use_graph=use_graph)
+        # host batches are copied straight into the step's (length-bucketed) input buffers: StepEngine._stage_batch
+        return eng.train_step(x, mask, weights, lr, weight_decay, clip, use_graph=use_graph)
 
     @torch.no_grad()
     def eval_step(self, x, mask, weights):
         eng = self._engine()
         x, mask = self._prep(x, mask)
-        dev = self.head_xyz.weight.device
-        return eng.eval_step(x.to(dev), mask.to(dev) if mask is not None else None, weights)
+        return eng.eval_step(x, mask, weights)
 
     def metric_names(self):
         return list(METRIC_KEYS)
@@ -511,9 +518,18 @@ class VQVAE(nn.Module):
         if eng.ctx is None or eng.ctx.get("loss_fwd_id") != eng.fwd_id:
             raise _L.VqhError("backward: no loss_function result for the engine's last forward (the loss was evaluated on "
                               "other tensors, or another forward ran in between)")
+        # torch semantics: gradients ACCUMULATE until they are consumed (engine optimizer step) or dropped
+        # (optimizer.zero_grad() -> p.grad None; zero_grad(set_to_none=False) zeroes the flat buffer in place).  The HIP
+        # backward overwrites the flat buffer, so a pending gradient is parked and added back.
+        probe = next(iter(self.parameters()))
+        pending = getattr(eng, "_grads_pending", False) and probe.grad is not None
+        parked = eng.flat_g.clone() if pending else None
         eng.backward()
         if float(grad_scale) != 1.0:                # (loss / accum).backward(), loss scaling
             eng.flat_g.mul_(float(grad_scale))
+        if parked is not None:
+            _L.call("vqh_add", eng.flat_g, parked, eng.flat_g, eng.flat_g.numel())
+        eng._grads_pending = True
         eng.attach_grads()
         if getattr(self, "_grad_monitor_enabled", False):
             self._report_grads()

@@ -5,11 +5,16 @@ Two-stage VQ-VAE training entry on MI355X -- same command line as the reference'
   python run.py -c configs/stage1_ae.yaml                                   # stage 1: AE pre-training
   python run.py -c configs/stage2_vq.yaml --warm_start_ckpt S1.ckpt --init_codebook centroids.npy
   python run.py -c configs/stage2_vq.yaml --resume_ckpt checkpoints/.../last.ckpt
-  torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run.py -c configs/stage2_vq.yaml   # 8 x MI355X, RCCL
+
+Multi-GPU like the reference (Lightning `devices: N, strategy: ddp`, run.py:191-218, configs/stage2_vq.yaml:209-212): with
+trainer_params.devices > 1 this one command starts N ranks itself (child processes, one per MI355X, RCCL over xGMI).
+Running it under torchrun works as well (the launcher's RANK / WORLD_SIZE win over `devices`):
+  torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run.py -c configs/stage2_vq.yaml
 """
 import argparse
 import os
 import random
+import sys
 import time
 from pathlib import Path
 
@@ -18,7 +23,7 @@ import torch
 import yaml
 
 from experiment import VQVAEExperiment
-from trainer import ModelCheckpoint, Trainer
+from trainer import ModelCheckpoint, ScalarLogger, Trainer
 
 
 def seed_everything(seed: int):
@@ -49,6 +54,29 @@ def maybe_init_codebook(model, path):
     print(f"[Codebook init] Loaded centroids {tuple(C.shape)} from {path}")
 
 
+def resolve_devices(trainer_params) -> int:
+    """trainer_params.devices as a rank count: int, "auto" / -1 (every visible GPU), a list of device ids, or a digit string.
+    Capped to the GPUs present (with a notice) unless the ranks are told to share devices over gloo (VQH_DIST_BACKEND=gloo:
+    the two-ranks-on-one-GPU tests)."""
+    from vqvae_hip import launch
+    dev = trainer_params.get("devices", 1)
+    ngpu = launch.visible_gpus()
+    if isinstance(dev, (list, tuple)):
+        n = len(dev)
+    elif isinstance(dev, str):
+        n = ngpu if dev.strip().lower() in ("auto", "-1") else int(dev)
+    else:
+        n = int(dev)
+        if n < 0:
+            n = ngpu
+    n = max(1, n)
+    if str(trainer_params.get("accelerator", "gpu")) == "gpu" and os.environ.get("VQH_DIST_BACKEND", "nccl") == "nccl" \
+            and ngpu >= 1 and n > ngpu:
+        print(f"[Launch] trainer_params.devices={n} but only {ngpu} GPU(s) are visible: using {ngpu}")
+        n = ngpu
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser(description="Train VQ-VAE (two-stage compatible) on MI355X.")
     ap.add_argument("--config", "-c", type=str, required=True, help="Path to YAML config file.")
@@ -62,6 +90,15 @@ def main():
     model_params, exp_params, data_params = cfg["model_params"], cfg["exp_params"], cfg["data_params"]
     trainer_params = dict(cfg.get("trainer_params", {}))
     logging_params = cfg.get("logging_params", {})
+
+    # `devices: N` + `strategy: ddp`: one process per GPU.  The parent has not touched the GPU yet; it starts the ranks as
+    # children (never a re-exec) and leaves with their exit code.  Inside a rank (RANK set) this block is skipped.
+    from vqvae_hip import launch
+    if not launch.under_launcher():
+        n_ranks = resolve_devices(trainer_params)
+        if n_ranks > 1:
+            print(f"[Launch] starting {n_ranks} ranks (strategy={trainer_params.get('strategy', 'ddp')}, one process per GPU)", flush=True)
+            raise SystemExit(launch.spawn_ranks(n_ranks, os.path.abspath(__file__), sys.argv[1:]))
 
     seed = exp_params.get("manual_seed", 42)
     seed_everything(seed)
@@ -99,8 +136,10 @@ def main():
     ckpt_dir = Path(exp_params.get("checkpoint_dir", "./checkpoints/aeot_sigmoid"))
     ckpt_cb = ModelCheckpoint(dirpath=str(ckpt_dir), filename=exp_params.get("checkpoint_name_pattern", "epochepoch={epoch:03d}"),
                               every_n_epochs=int(exp_params.get("save_every_epochs", 10)), save_last=True, save_top_k=-1)
+    logger_name = logging_params.get("name", model_params.get("name", "VQVAE")) + ("-resume" if resume else "")
+    logger = ScalarLogger(logging_params.get("save_dir", "./logs"), logger_name)
     clip = trainer_params.pop("gradient_clip_val", 5.0)
-    trainer = Trainer(callbacks=[ckpt_cb], gradient_clip_val=clip, **trainer_params)
+    trainer = Trainer(logger=logger, callbacks=[ckpt_cb], gradient_clip_val=clip, **trainer_params)
 
     print("======= Training {} =======".format(model_params.get("name", "VQVAE")))
     print("use_vq =", model_params.get("use_vq", True))

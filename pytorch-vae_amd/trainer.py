@@ -29,6 +29,31 @@ class ModelCheckpoint:
             trainer.save_checkpoint(os.path.join(self.dirpath, "last.ckpt"))
 
 
+class ScalarLogger:
+    """Stand-in for the reference's TensorBoardLogger (run.py:166-170): the scalars the harness logs (train/*, val/*, epoch/*,
+    lr) appended as JSON lines to <save_dir>/<name>/version_<n>/scalars.jsonl by rank 0.  No tensorboard dependency."""
+
+    def __init__(self, save_dir, name):
+        self.root = os.path.join(str(save_dir), str(name))
+        self.path = None
+
+    def _open(self):
+        if self.path is None:
+            os.makedirs(self.root, exist_ok=True)
+            taken = [int(d.split("_")[1]) for d in os.listdir(self.root) if d.startswith("version_") and d.split("_")[1].isdigit()]
+            vdir = os.path.join(self.root, f"version_{max(taken) + 1 if taken else 0}")
+            os.makedirs(vdir, exist_ok=True)
+            self.path = os.path.join(vdir, "scalars.jsonl")
+        return self.path
+
+    def log_metrics(self, metrics, step):
+        import json
+        rec = {"step": int(step)}
+        rec.update({k: float(v) for k, v in metrics.items()})
+        with open(self._open(), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
 class Trainer:
     def __init__(self, max_epochs=1, gradient_clip_val=0.0, callbacks: Optional[List] = None, limit_val_batches=1.0,
                  limit_train_batches=1.0, accelerator="gpu", devices=1, strategy="ddp", logger=None, **ignored):
@@ -65,6 +90,8 @@ class Trainer:
         exp.trainer, exp.global_rank = self, self.global_rank
         self.ckpt_path = ckpt_path
         if self.accelerator == "gpu":
+            if not torch.cuda.is_available():
+                raise RuntimeError("Trainer(accelerator='gpu'): no MI355X visible -- the HIP training step has no CPU fallback")
             exp.model = exp.model.to(torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()))
         exp.setup("fit")
         policy = exp.configure_optimizers()
@@ -97,6 +124,11 @@ class Trainer:
                 exp.on_validation_epoch_end()
                 exp.model.train()
             exp.on_train_epoch_end()
+            if self.logger is not None and self.global_rank == 0 and getattr(exp, "logged", None):
+                rec = dict(exp.logged, epoch=epoch)
+                if policy is not None:
+                    rec["lr"] = policy.current()[0]            # LearningRateMonitor(logging_interval="epoch"), run.py:186
+                self.logger.log_metrics(rec, self.global_step)
             if policy is not None:
                 policy.on_epoch()
             for cb in self.callbacks:

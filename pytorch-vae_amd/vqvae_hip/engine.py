@@ -63,6 +63,16 @@ def bwd_phases(num_layers):
     return tuple(dec) + (("tokenizer.", "to_code."), ("fuse_mlp.", "ln_ss.", "ss_encoder.", "ss_input_proj.")) + tuple(geo)
 
 
+def bucket_length(L0, granule, max_seq_len):
+    """Padded sequence length of the fused step: the next multiple of `granule`, capped at max_seq_len (pos_enc and
+    query_embed have max_seq_len rows: models/vq_vae.py:639-650, :750-751).  L <= 350 at granule 32 -> 32, 64, ..., 320, 350:
+    11 shapes instead of one per distinct L_max, and B*L a multiple of the 256-row GEMM tile for every even batch >= 8."""
+    L0, g = int(L0), int(granule)
+    if g <= 1:
+        return L0
+    return int(min(-(-L0 // g) * g, max(int(max_seq_len), L0)))
+
+
 def _bwd_phase(name, phases):
     for i, prefixes in enumerate(phases):
         if name.startswith(prefixes):
@@ -102,6 +112,7 @@ class _Arena:
 
 
 MAX_GRAPHS_PER_ARENA = 4
+HYPER_SLOTS = 4          # pinned host copies of the per-step scalars in flight = how many steps the host may run ahead
 
 
 class StepEngine:
@@ -122,7 +133,11 @@ class StepEngine:
         # batch-shape arenas (see _Arena): real data has a different L_max per batch (dataset.py:30-49) and a validation
         # pass between train epochs (experiment.py:478-479); each shape keeps its own buffers + graphs, LRU-bounded
         self.arenas = collections.OrderedDict()
-        self.max_arenas = int(os.environ.get("VQH_MAX_ARENAS", "8"))
+        self.max_arenas = int(os.environ.get("VQH_MAX_ARENAS", "16"))     # > the 11 length buckets of L <= 350 (bucket_len)
+        # Length bucketing of the fused train / eval step (real data: pad_collate pads every batch to its OWN L_max,
+        # /root/reference/dataset.py:30-49): L_max is padded up to a multiple of `len_bucket` (mask False on the tail, every
+        # kernel is mask-aware), so that few arenas / graphs exist and B*L stays a multiple of the 256-row GEMM tile.
+        self.len_bucket = int(os.environ.get("VQH_LEN_BUCKET", "32"))
         self.max_arena_bytes = int(float(os.environ.get("VQH_ARENA_GIB", "0")) * (1 << 30)) or \
             int(0.6 * torch.cuda.get_device_properties(self.dev).total_memory)
         self.arena = None
@@ -137,6 +152,7 @@ class StepEngine:
         self._sites = {}
         self._flatten()
         self.hyper = torch.zeros(9, device=self.dev, dtype=torch.float32)
+        self._hyper_host, self._hyper_ev = None, None
         self.metrics_acc = torch.zeros(len(METRIC_KEYS), device=self.dev, dtype=torch.float32)
         self._pending_ema = None
         self.fwd_id = 0                            # incremented by every forward: ties loss_function/backward to it
@@ -231,6 +247,35 @@ class StepEngine:
             torch.cuda.synchronize(self.dev)        # nothing in flight may still address the evicted buffers
             self.arenas.pop(old_key).release()
         return a
+
+    def bucket_len(self, L0):
+        return bucket_length(L0, self.len_bucket, self.m.max_seq_len)
+
+    def _stage_batch(self, x, mask):
+        """Copy the batch into the bucketed input buffers of the current shape's arena (outside any graph): x [B, L0, 6] ->
+        in.x [B, Lb, 6] zero padded, mask -> in.mask [B, Lb] with False on the padded tail.  x / mask may live on the host:
+        a pinned batch (DataLoader pin_memory) then goes host -> arena in ONE asynchronous copy, queued behind the previous
+        step's graph on the same stream (C2: 0.4 MB, ~10 us) -- there is no intermediate device tensor.  Returns (arena, x, mask); the
+        mask stays None when the caller passed none and nothing was padded (the reference's mask=None variant)."""
+        B, L0 = int(x.shape[0]), int(x.shape[1])
+        Lb = self.bucket_len(L0)
+        a = self.use_arena((B, Lb))
+        xt = self.T("in.x", B, Lb, int(x.shape[2]))
+        if Lb == L0:
+            xt.copy_(x, non_blocking=True)
+        else:
+            xt[:, :L0].copy_(x, non_blocking=True)
+            xt[:, L0:].zero_()
+        ms = None
+        if mask is not None or Lb != L0:
+            ms = self.T("in.mask", B, Lb, dtype=torch.bool)
+            if mask is not None:
+                ms[:, :L0].copy_(mask, non_blocking=True)
+            else:
+                ms[:, :L0].fill_(True)
+            if Lb != L0:
+                ms[:, L0:].fill_(False)
+        return a, xt, ms
 
     def T(self, name, *shape, dtype=torch.float32):
         """Named device buffer of the current arena.  (name, shape, dtype) always maps to the same storage, so a graph
@@ -1042,14 +1087,29 @@ class StepEngine:
         """Host -> device scalars of the next optimizer step (copied on the current stream, outside any graph)."""
         self.opt_step += 1
         t = self.opt_step
-        h = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, max_norm if max_norm else 0.0,
-                          1.0 - betas[0] ** t, 1.0 - betas[1] ** t, grad_scale], dtype=torch.float32)
-        self.hyper.copy_(h, non_blocking=False)
+        # pinned staging ring + asynchronous copy: a pageable-memory copy would make the host wait for the previous step's
+        # graph every step; the ring's events bound the host's run-ahead to HYPER_SLOTS steps instead
+        if self._hyper_host is None:
+            self._hyper_host = [torch.empty(9, dtype=torch.float32).pin_memory() for _ in range(HYPER_SLOTS)]
+            self._hyper_ev = [None] * HYPER_SLOTS
+        slot = t % HYPER_SLOTS
+        if self._hyper_ev[slot] is not None:
+            self._hyper_ev[slot].synchronize()
+        hb = self._hyper_host[slot]
+        vals = [lr, betas[0], betas[1], eps, weight_decay, max_norm if max_norm else 0.0,
+                1.0 - betas[0] ** t, 1.0 - betas[1] ** t, grad_scale]
+        for i, v in enumerate(vals):
+            hb[i] = float(v)
+        self.hyper.copy_(hb, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_ev[slot] = ev
 
     def optimizer_step(self):
         """clip_grad_norm_(max_norm) + AdamW over the flat buffers (hyper-parameters from self.hyper)."""
         call("vqh_grad_norm", self.flat_g, self.n_flat, self.hyper, self.norm, self.norm_ws)
         call("vqh_adamw_step", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n_flat, self.hyper, self.norm)
+        self._grads_pending = False                 # consumed: the next backward() overwrites instead of accumulating
 
     def world(self):
         from .parallel import world_size
@@ -1149,9 +1209,7 @@ class StepEngine:
         m = self.m
         self.train = True
         self.defer_ema = not (m.use_vq and float(m.usage_entropy_lambda) > 0.0)   # the regulariser reads the refreshed table
-        a = self.use_arena((int(x.shape[0]), int(x.shape[1])))
-        xt = self.T("in.x", *x.shape)
-        xt.copy_(x, non_blocking=True)
+        a, xt, ms = self._stage_batch(x, mask)    # length-bucketed arena; padded tail masked out
         x_in = self.augment_input(xt)             # eager, outside the graph (fresh torch random draws every step)
         upd = self._host_prologue()
         world = self.world()
@@ -1160,15 +1218,11 @@ class StepEngine:
         self.set_hyper(lr, weight_decay, clip, betas=getattr(self, "betas", (0.9, 0.999)), grad_scale=1.0 / world)
         decay = float(m.quantizer.decay) if m.use_vq else 0.0
         # everything a captured graph bakes in as a kernel argument (the batch shape is the arena)
-        key = (mask is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
+        key = (ms is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
                world, dp, self.drop_scale, float(m.quantizer.beta) if m.use_vq else 0.0, float(m.label_smoothing or 0.0),
                x_in is xt, float(m.usage_entropy_lambda), self._soft_vq_key(), self.share_layer0, self.fold_dropout_bwd, self.group_wgrad,
                float(m.xyz_align_alpha), float(m.ss_tv_lambda), m._data_std is not None)
         xs = x_in
-        ms = None
-        if mask is not None:
-            ms = self.T("in.mask", *mask.shape, dtype=torch.bool)
-            ms.copy_(mask, non_blocking=True)
         use_graph = bool(use_graph) and os.environ.get("VQH_GRAPH", "1") != "0"
         segs = a.graphs.get(key) if use_graph else None
         if segs is not None:
@@ -1232,10 +1286,10 @@ class StepEngine:
     def eval_step(self, x, mask, weights):
         self.train = False
         self.defer_ema = False
-        self.use_arena((int(x.shape[0]), int(x.shape[1])))
+        _, xt, ms = self._stage_batch(x, mask)
         upd = self._host_prologue()
-        rec, z_e, z_q, idx, stats = self._forward_core(x, mask, upd)
-        self.loss(rec, x, mask, z_e, z_q, stats, weights)
+        rec, z_e, z_q, idx, stats = self._forward_core(xt, ms, upd)
+        self.loss(rec, xt, ms, z_e, z_q, stats, weights)
         return self.metrics
 
     def advance_rng(self):

@@ -79,10 +79,18 @@ def lib():
             fn.restype = C.c_int
         # process-wide A/B switches of the kernel families (see include/vqvae_hip.h), e.g. VQH_GEMM_FLAGS=513 runs every
         # large GEMM tile on the native fp32 MFMA instead of the split-operand bf16 tiles, VQH_VQ_FLAGS=2 the same for VQ scores
-        for env, setter in (("VQH_GEMM_FLAGS", "vqh_gemm_set_flags"), ("VQH_VQ_FLAGS", "vqh_vq_set_flags"),
-                            ("VQH_ATTN_FLAGS", "vqh_attn_set_flags")):
+        # The bits that produce WRONG results (timing-only: skip stores / loads) are refused here and masked off by the
+        # product build of the library itself (-DVQH_DIAG labs only); every override is announced once on stderr.
+        for env, setter, bad in (("VQH_GEMM_FLAGS", "vqh_gemm_set_flags", 2 | 4), ("VQH_VQ_FLAGS", "vqh_vq_set_flags", 0),
+                                 ("VQH_ATTN_FLAGS", "vqh_attn_set_flags", 0)):
             if os.environ.get(env):
-                getattr(L, setter)(int(os.environ[env]))
+                val = int(os.environ[env])
+                if val & bad:
+                    raise VqhError(f"{env}={val}: bits {val & bad} are result-corrupting timing diagnostics, not available "
+                                   f"in the product library")
+                getattr(L, setter)(val)
+                import sys
+                print(f"[vqvae_hip] {env}={val} applied ({setter}): kernel A/B override for this process", file=sys.stderr)
         _lib = L
     return _lib
 

@@ -141,6 +141,11 @@ def vq_case(name, B, M, K_per, D, Q, seed, steps=1, centroid_init=False, train=T
                 out[f"emb_head_{s}"] = np_(ref.embedding[:16])
             out[f"ep_usage_{s}"] = np_(ref._ep_usage)
             out[f"ep_cnt_{s}"] = np_(ref._ep_cnt)
+            # get_epoch_stats() of the reference itself (models/vq_vae.py:118-164): the dict the harness prints per epoch
+            es = ref.get_epoch_stats()
+            out[f"epstats_{s}"] = np.array([float(es["perplexity"]), float(es["dead_ratio"]), float(es["n_positions"]),
+                                            float(es["margin_mean"]), float(es["qe_mean"]), float(es["qe_p90"])], dtype=np.float64)
+            assert np.array_equal(np_(es["usage_hist"]), np_(ref._ep_usage))
     if store_inputs:
         out["z_0_full"] = np_(z_all[0])
         out["emb0_full"] = np_(emb0)
@@ -357,7 +362,7 @@ def _extract_function(path, fn_name, namespace):
     import ast
     src = open(path).read()
     tree = ast.parse(src)
-    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fn_name)
+    node = next(n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name == fn_name)
     mod = ast.Module(body=[node], type_ignores=[])
     exec(compile(mod, f"<{os.path.basename(path)}:{fn_name}>", "exec"), namespace)
     return namespace[fn_name]
@@ -426,6 +431,65 @@ def harness_case(name="harness"):
     print(f"[golden] {name}: schedules of both YAMLs (epochs 0-200), pad_collate, OneCycle / cosine traces")
 
 
+# ------------------------------------------------------------------------------------------
+# 6. CurveDataset (dataset.py:54-139) on the file formats it accepts: np.save'd dict (.npy), .npz, a file holding NaN / Inf;
+#    and the two shape errors.  The class is cut out of the reference source with ast (its module imports Lightning).
+# ------------------------------------------------------------------------------------------
+def dataset_case(name="dataset"):
+    import tempfile
+    from pathlib import Path
+    from typing import Optional
+    from torch.utils.data import Dataset
+    RefDS = _extract_function(os.path.join(REF, "dataset.py"), "CurveDataset",
+                              {"Dataset": Dataset, "Optional": Optional, "Path": Path, "os": os, "np": np, "torch": torch})
+    rs = np.random.RandomState(77)
+    lens = [7, 12, 5]
+    curves = []
+    for i, n in enumerate(lens):
+        xyz = (rs.randn(n, 3) * 4.0 + np.array([10.0, -3.0, 0.5]) * (i + 1)).astype(np.float32)
+        ss = np.eye(3, dtype=np.float32)[rs.randint(0, 3, n)]
+        curves.append((xyz, ss))
+    curves[2][0][1, 2] = np.nan                    # sanitised to 0 after centring (dataset.py:135-137)
+    curves[2][0][3, 0] = np.inf
+    out = {"lens": np.array(lens)}
+    with tempfile.TemporaryDirectory() as tmp:
+        names = ["a.npy", "b.npz", "c.npy"]
+        np.save(os.path.join(tmp, names[0]), {"curve_coords": curves[0][0], "ss_one_hot": curves[0][1]}, allow_pickle=True)
+        np.savez(os.path.join(tmp, names[1]), curve_coords=curves[1][0], ss_one_hot=curves[1][1])
+        np.save(os.path.join(tmp, names[2]), {"curve_coords": curves[2][0], "ss_one_hot": curves[2][1]}, allow_pickle=True)
+        np.save(os.path.join(tmp, "bad_xyz.npy"), {"curve_coords": curves[0][0][:, :2], "ss_one_hot": curves[0][1]}, allow_pickle=True)
+        np.save(os.path.join(tmp, "bad_ss.npy"), {"curve_coords": curves[0][0], "ss_one_hot": curves[0][1][:-1]}, allow_pickle=True)
+        lst = os.path.join(tmp, "list.txt")
+        open(lst, "w").write("\n".join(names) + "\n\n")
+        ds = RefDS(tmp, list_path=lst, train=True)
+        assert len(ds) == 3
+        for i in range(3):
+            out[f"in_xyz_{i}"], out[f"in_ss_{i}"] = curves[i]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out[f"item_{i}"] = np_(ds[i])
+        for j, bad in enumerate(["bad_xyz.npy", "bad_ss.npy"]):
+            open(lst, "w").write(bad + "\n")
+            try:
+                RefDS(tmp, list_file=lst, train=False)[0]
+                out[f"bad_{j}_raises"] = 0
+            except ValueError:
+                out[f"bad_{j}_raises"] = 1
+        open(lst, "w").write("\n")
+        try:
+            RefDS(tmp, list_path=lst)
+            out["empty_list_raises"] = 0
+        except FileNotFoundError:
+            out["empty_list_raises"] = 1
+        try:
+            RefDS(tmp)
+            out["no_list_raises"] = 0
+        except ValueError:
+            out["no_list_raises"] = 1
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"[golden] {name}: CurveDataset on .npy dict / .npz / NaN file, shape errors")
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     want = lambda n: (not only) or (n in only)
@@ -463,6 +527,8 @@ if __name__ == "__main__":
         loss_case("loss_short", 3, 9, 33, False, G.ALL_LOSS_WEIGHTS, G.SMALL_VQ)
     if want("harness"):
         harness_case()
+    if want("dataset"):
+        dataset_case()
     if want("init"):
         init_case("init_small_vq_seed1265", G.SMALL_VQ, 1265)
         init_case("init_c2_seed1265", G.C2_MODEL, 1265)

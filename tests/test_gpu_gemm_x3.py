@@ -206,3 +206,66 @@ def test_vq_nearest_on_the_bf16_pipes_returns_the_fp64_argmin(R, K, D):
             a, b = float(d64[r, idx[r]]), float(d64[r, ref[r]])
             assert abs(a - b) <= 1e-12 * max(1.0, abs(b)) and int(idx[r]) < int(ref[r]) + K, (flags, r, int(idx[r]), int(ref[r]), a, b)
         assert len(bad) <= 8, (flags, len(bad))
+
+
+# ---------------------------------------------------------------------------------------------- domain edges of the split
+def _gemm_both(L, A, B, M, N, K):
+    ws = torch.empty(1 << 22, device=DEV)
+    out = {}
+    for name, extra in (("x3", 0), ("native", NATIVE)):
+        with flags(L, extra):
+            C = torch.full((M, N), float("nan"), device=DEV)
+            L.gemm(1, 1, M, N, K, A, K, B, K, C, N, ws=ws)
+            out[name] = C
+    return out
+
+
+@pytest.mark.parametrize("log2_scale", [-100, -108, -120])
+def test_x3_small_magnitude_operands(log2_scale):
+    """The guaranteed domain stated in include/vqvae_hip.h: for finite operands with 2^-100 <= |a| <= 3.38e38 the split is exact
+    (m and l are normal bf16 numbers) and the product is as accurate as the fp32 MFMA's.  Below 2^-100 the low planes reach the
+    bf16 denormal range (m below 2^-117, l below 2^-108): whatever the matrix pipe does with them, the result keeps at least the
+    high plane's 8 bits, the error stays below 2^-8 of the dot product's magnitude sum -- in absolute terms below
+    2^-108 * |b|, far under the round-off of any quantity a training step adds it to."""
+    L = _hip()
+    M, N, K = 512, 256, 256
+    g = torch.Generator(device="cpu").manual_seed(100 - log2_scale)
+    A = (torch.randn(M, K, generator=g) * 2.0 ** log2_scale).to(DEV)
+    B = torch.randn(N, K, generator=g).to(DEV)
+    ref = A.double() @ B.double().t()
+    mag = A.double().abs() @ B.double().abs().t()
+    out = _gemm_both(L, A, B, M, N, K)
+    e = {k: float(((v.double() - ref).abs() / mag).max()) for k, v in out.items()}
+    print(f"scale 2^{log2_scale}: max |err| / sum|a||b|: x3 {e['x3']:.3e}, native fp32 MFMA {e['native']:.3e}")
+    assert torch.isfinite(out["x3"]).all()
+    if log2_scale >= -100:
+        assert e["x3"] <= max(1.5 * e["native"], 2.0 ** -22), e
+    else:
+        assert e["x3"] <= 2.0 ** -8, e
+
+
+def test_x3_fp32_denormal_operands_and_large_magnitudes():
+    """fp32 denormal operands: products are below fp32's normal range; both arithmetics must return finite values with an
+    absolute error below 2^-120 (they may flush).  Large magnitudes: up to 3.38e38 (bf16's largest finite value is 3.3895e38)
+    an identity product is exact; above it the high plane rounds to Inf and the product is NaN where the fp32 MFMA returns the
+    value -- documented in include/vqvae_hip.h: the top 0.4 % of fp32's range, where a training run has diverged anyway."""
+    L = _hip()
+    M, N, K = 256, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = (torch.randn(M, K, generator=g) * 1e-40).to(DEV)
+    B = torch.randn(N, K, generator=g).to(DEV)
+    out = _gemm_both(L, A, B, M, N, K)
+    ref = A.double() @ B.double().t()
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+        assert float((v.double() - ref).abs().max()) < 2.0 ** -120, k
+    eye = torch.eye(K, device=DEV)
+    X = torch.randn(M, K, generator=g).sign().to(DEV) * 3.38e38
+    X[0, 0] = 1.0e38
+    X[1, 1] = -3.3e38
+    out = _gemm_both(L, X, eye[:N].contiguous(), M, N, K)
+    assert torch.equal(out["x3"], X[:, :N]) and torch.equal(out["native"], X[:, :N])
+    X[3, 5] = 3.3999e38                                   # finite in fp32, rounds to Inf in bf16
+    out = _gemm_both(L, X, eye[:N].contiguous(), M, N, K)
+    assert torch.isnan(out["x3"][3, 5]) or float(out["x3"][3, 5]) == float(X[3, 5])
+    assert torch.equal(out["x3"][4:], X[4:, :N])          # other rows unaffected

@@ -26,7 +26,8 @@ def _cfg(base, tmp, name, **over):
                               synthetic={"n": 64, "n_val": 16, "max_len": 48, "min_len": 30, "seed": 3})
     cfg["exp_params"].update(checkpoint_dir=os.path.join(tmp, name), save_every_epochs=1, print_every=2)
     cfg["exp_params"].update(over.pop("exp", {}))
-    cfg["trainer_params"].update(max_epochs=over.pop("epochs", 2), devices=1, limit_val_batches=1.0)
+    cfg["trainer_params"].update(max_epochs=over.pop("epochs", 2), devices=over.pop("devices", 1), limit_val_batches=1.0)
+    cfg["logging_params"] = {"save_dir": os.path.join(tmp, "logs"), "name": name}
     path = os.path.join(tmp, name + ".yaml")
     yaml.safe_dump(cfg, open(path, "w"))
     return path
@@ -68,19 +69,38 @@ def test_two_stage_training_through_run_py(tmp_path):
 
 
 def test_two_rank_training_through_run_py(tmp_path):
-    """Same entry under torch.distributed.run with 2 ranks (sharing the one GPU, hence gloo): DistributedSampler shards,
-    the single [grads | EMA stats] all-reduce keeps the ranks' weights identical, rank 0 writes the checkpoints."""
+    """The reference's single command (`python run.py -c cfg` with trainer_params.devices: 2, strategy ddp; run.py:191-218):
+    run.py starts the 2 ranks itself as child processes (sharing the one GPU here, hence gloo).  DistributedSampler shards,
+    the [grads | EMA stats] all-reduce keeps the ranks' weights identical, rank 0 writes checkpoints and the scalar log."""
     tmp = str(tmp_path)
-    s2 = _cfg("stage2_vq.yaml", tmp, "ddp", model=dict(num_quantizers=1, codebook_size=32), epochs=2)
+    s2 = _cfg("stage2_vq.yaml", tmp, "ddp", model=dict(num_quantizers=1, codebook_size=32), epochs=2, devices=2)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PYTHONPATH=PKG, VQH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "run.py"), "-c", s2], cwd=PKG, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "[Launch] starting 2 ranks" in r.stdout and "[Epoch 1]" in r.stdout
+    ck = torch.load(os.path.join(tmp, "ddp", "last.ckpt"), map_location="cpu", weights_only=True)
+    assert ck["epoch"] == 1 and ck["global_step"] == 2 * (64 // 2 // 16)        # 64 samples / 2 ranks / batch 16, 2 epochs
+    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.dtype.is_floating_point)
+    import glob
+    import json
+    logs = glob.glob(os.path.join(tmp, "logs", "ddp", "version_0", "scalars.jsonl"))
+    assert len(logs) == 1
+    recs = [json.loads(ln) for ln in open(logs[0])]
+    assert len(recs) == 2 and recs[-1]["epoch"] == 1 and "epoch/loss" in recs[-1] and "lr" in recs[-1]
+
+
+def test_two_rank_training_under_torchrun(tmp_path):
+    """The same entry under an external launcher (RANK / WORLD_SIZE exported): run.py must not spawn a second generation."""
+    tmp = str(tmp_path)
+    s2 = _cfg("stage2_vq.yaml", tmp, "ddp2", model=dict(num_quantizers=1, codebook_size=32), epochs=1, devices=2)
     env = dict(os.environ, PYTHONPATH=PKG, VQH_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(PKG, "run.py"), "-c", s2],
                        cwd=PKG, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "[Epoch 1]" in r.stdout
-    ck = torch.load(os.path.join(tmp, "ddp", "last.ckpt"), map_location="cpu", weights_only=True)
-    assert ck["epoch"] == 1 and ck["global_step"] == 2 * (64 // 2 // 16)        # 64 samples / 2 ranks / batch 16, 2 epochs
-    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.dtype.is_floating_point)
+    assert "[Launch]" not in r.stdout and "[Epoch 0]" in r.stdout
 
 
 def test_generate_sample_and_autograd_bridge_api():

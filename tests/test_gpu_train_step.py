@@ -83,7 +83,7 @@ def test_fused_train_step_matches_reference_golden(name, cfg_kw, _r, mode):
             assert_scalar(md[str(k)], g[f"loss_vals_{s}"][i], g[f"loss_vals64_{s}"][i], f"{name} step {s} loss[{k}]",
                           rel=1e-5 if s == 0 else 3e-5)
         B, L = x.shape[0], x.shape[1]
-        assert_tensor(eng.buf["dec.recons"].view(B, L, 6), g[f"recons_{s}"], g[f"recons_err64_{s}"], f"recons_{s}")
+        assert_tensor(eng.buf["dec.recons"].view(B, -1, 6)[:, :L], g[f"recons_{s}"], g[f"recons_err64_{s}"], f"recons_{s}")
         assert_tensor(eng.buf["tok.z_e"], g[f"z_e_{s}"], g[f"z_e_err64_{s}"], f"z_e_{s}")
         if m.use_vq:
             got = eng.buf["vq.idx"].cpu().numpy().astype(np.int32)
@@ -337,3 +337,73 @@ def test_nan_row_gives_nan_loss_not_a_fault():
     ok = torch.ones(4, 8, dtype=torch.bool)
     ok[1, 3] = ok[2, 0] = False
     assert torch.equal(idx.cpu()[ok], ref[ok])
+
+
+# ---------------------------------------------------------------------------------------------- length bucketing (round 3)
+def _flat_state(eng):
+    return eng.flat_g.clone(), eng.metrics.clone(), eng.buf["vq.idx"].clone(), eng.norm.clone()
+
+
+def test_bucketed_step_equals_unpadded_step():
+    """Real data pads every batch to its own L_max (reference dataset.py:30-49); the fused step pads L_max further, to a
+    bucket (StepEngine.bucket_len), with the mask False on the tail.  The padded step must equal the un-padded one at every
+    valid position: code indices bit-exact, all 24 metrics, the gradient norm and every gradient tensor under the parity rule."""
+    from vqvae_hip.engine import METRIC_KEYS
+    cfg_kw = dict(G.SMALL_VQ)
+    sd0 = G.model_state(cfg_kw, 77)
+    weights = dict(G.ALL_LOSS_WEIGHTS)
+    x, mask = G.smooth_curve_batch(5, 27, 78, ragged=True)
+    outs = {}
+    for gran in (1, 32):
+        m, eng = _model(cfg_kw, sd0)
+        m.training_steps = 1
+        eng.len_bucket = gran
+        m.train_step(x, mask, weights, 1e-3, 0.01, 1.0, use_graph=False)
+        torch.cuda.synchronize()
+        assert eng.arena.key == (5, 27 if gran == 1 else 32)
+        outs[gran] = (_flat_state(eng), {k: eng.G[k].clone() for k in eng.G}, eng.buf["dec.recons"].view(5, -1, 6)[:, :27].clone())
+    (g1, met1, idx1, n1), G1, rec1 = outs[1]
+    (g2, met2, idx2, n2), G2, rec2 = outs[32]
+    assert torch.equal(idx1, idx2), "code indices must not depend on the padding"
+    for k, a, b in zip(METRIC_KEYS, met1.tolist(), met2.tolist()):
+        assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, (k, a, b)
+    assert abs(float(n1[0]) - float(n2[0])) <= 1e-5 * float(n1[0])
+    valid = mask.to(rec1.device)[..., None]
+    assert_tensor(rec2 * valid, rec1 * valid, None, "reconstructions at valid positions")
+    for k in G1:
+        assert_tensor(G2[k], G1[k], None, f"grad {k}", rel=2e-5, floor=1e-7 * float(g1.abs().max()))
+
+
+def test_many_raw_lengths_share_buckets_and_reach_graph_mode():
+    """More distinct raw L_max values than VQH_MAX_ARENAS used to mean: a fresh arena, an eager step and an eviction almost
+    every step.  With buckets, 14 distinct lengths land in 2 arenas and replay graphs from their third visit on; the replayed,
+    padded steps follow an eager un-padded run of the same batches (same weights trajectory)."""
+    cfg_kw = dict(G.SMALL_VQ, max_seq_len=350)
+    sd0 = G.model_state(cfg_kw, 91)
+    weights = dict(G.BASE_LOSS_WEIGHTS)
+    lens = [40, 64, 33, 51, 70, 96, 65, 88, 47, 59, 77, 91, 36, 83]
+    seq = [G.curve_batch(4, L, 900 + i, ragged=True) for i, L in enumerate(lens)]
+    runs = {}
+    for bucketed in (True, False):
+        m, eng = _model(cfg_kw, sd0)
+        m.training_steps = 1
+        eng.len_bucket = 32 if bucketed else 1
+        eng.max_arenas = 8
+        mets, idxs, modes = [], [], []
+        for x, mask in seq:
+            m.train_step(x, mask, weights, 3e-4, 0.01, 1.0, use_graph=bucketed)
+            mets.append(eng.metrics.clone()); idxs.append(eng.buf["vq.idx"].clone()); modes.append(eng.last_step_mode)
+        torch.cuda.synchronize()
+        runs[bucketed] = (eng, mets, idxs, modes)
+    eb, metb, idxb, modes = runs[True]
+    eu, metu, idxu, _ = runs[False]
+    shapes = sorted(k for k in eb.arenas if k != ("init",))
+    assert shapes == [(4, 64), (4, 96)], shapes
+    assert modes[:4] == ["eager", "capture", "graph", "graph"] and modes[4:7] == ["eager", "capture", "graph"]
+    assert all(mo == "graph" for mo in modes[7:]), modes
+    assert len([k for k in eu.arenas if k != ("init",)]) <= 8                      # the un-bucketed run churned through 14 shapes
+    for i in range(len(seq)):
+        assert torch.equal(idxb[i], idxu[i]), f"step {i}: code indices differ between bucketed-graph and un-padded eager"
+        a, b = metb[i][0].item(), metu[i][0].item()
+        assert abs(a - b) <= 2e-3 * abs(b), (i, a, b)                               # trajectory tolerance (ReLU flips, DESIGN s3)
+    assert_norm_close(eb.flat_p, eu.flat_p, None, "weights after 14 steps", rel=1e-4)

@@ -307,3 +307,106 @@ def test_backward_phase_buckets_cover_every_parameter():
             for n, ph in zip(names, phases):
                 size[ph] += int(np.prod(shapes[n]))
             assert size[-1] / sum(size) < 0.10, size
+
+
+# ---------------------------------------------------------------------------------------------- round 3: real-data path
+def test_curve_dataset_matches_reference_on_npy_npz_and_bad_files(tmp_path):
+    """CurveDataset (reference dataset.py:54-139) on an np.save'd dict, an .npz and a file with NaN / Inf; the two shape
+    errors and the list-file errors.  Expected items come from the reference's own class (tests/golden/dataset.npz)."""
+    from dataset import CurveDataset, pad_collate
+    g = load_golden("dataset")
+    tmp = str(tmp_path)
+    names = ["a.npy", "b.npz", "c.npy"]
+    cur = [(g[f"in_xyz_{i}"], g[f"in_ss_{i}"]) for i in range(3)]
+    np.save(os.path.join(tmp, names[0]), {"curve_coords": cur[0][0], "ss_one_hot": cur[0][1]}, allow_pickle=True)
+    np.savez(os.path.join(tmp, names[1]), curve_coords=cur[1][0], ss_one_hot=cur[1][1])
+    np.save(os.path.join(tmp, names[2]), {"curve_coords": cur[2][0], "ss_one_hot": cur[2][1]}, allow_pickle=True)
+    np.save(os.path.join(tmp, "bad_xyz.npy"), {"curve_coords": cur[0][0][:, :2], "ss_one_hot": cur[0][1]}, allow_pickle=True)
+    np.save(os.path.join(tmp, "bad_ss.npy"), {"curve_coords": cur[0][0], "ss_one_hot": cur[0][1][:-1]}, allow_pickle=True)
+    lst = os.path.join(tmp, "list.txt")
+    open(lst, "w").write("\n".join(names) + "\n\n")
+    ds = CurveDataset(tmp, list_path=lst, train=True)
+    assert len(ds) == 3
+    items = []
+    for i in range(3):
+        with np.errstate(all="ignore"):
+            it = ds[i]
+        assert it.dtype == torch.float32 and tuple(it.shape) == (int(g["lens"][i]), 6)
+        assert np.array_equal(it.numpy(), g[f"item_{i}"]), f"item {i} differs from the reference's CurveDataset"
+        items.append(it)
+    x, mask = pad_collate(items)
+    assert tuple(x.shape) == (3, 12, 6) and mask.sum(1).tolist() == [7, 12, 5]
+    for j, bad in enumerate(["bad_xyz.npy", "bad_ss.npy"]):
+        open(lst, "w").write(bad + "\n")
+        assert int(g[f"bad_{j}_raises"]) == 1
+        with pytest.raises(ValueError):
+            CurveDataset(tmp, list_file=lst, train=False)[0]
+    open(lst, "w").write("\n")
+    assert int(g["empty_list_raises"]) == 1 and int(g["no_list_raises"]) == 1
+    with pytest.raises(FileNotFoundError):
+        CurveDataset(tmp, list_path=lst)
+    with pytest.raises(ValueError):
+        CurveDataset(tmp)
+
+
+def test_length_buckets():
+    """bucket_length: L <= 350 collapses to 11 padded lengths (32 ... 320, 350), all within VQH_MAX_ARENAS' default, and at the
+    reference's train_batch_size 128 every bucket keeps B*L on the 256-row GEMM tile."""
+    from vqvae_hip.engine import bucket_length
+    buckets = sorted({bucket_length(L, 32, 350) for L in range(1, 351)})
+    assert buckets == list(range(32, 321, 32)) + [350]
+    assert all(bucket_length(L, 32, 350) >= L for L in range(1, 351))
+    assert all((128 * b) % 256 == 0 for b in buckets)
+    assert bucket_length(37, 1, 350) == 37 and bucket_length(37, 0, 350) == 37          # bucketing off
+    assert bucket_length(40, 32, 40) == 40 and bucket_length(33, 32, 40) == 40         # capped at max_seq_len
+    assert bucket_length(400, 32, 350) == 400                                          # never shorter than the batch
+
+
+def test_get_epoch_stats_dict_matches_reference():
+    """VectorQuantizerEMA.get_epoch_stats() (models/vq_vae.py:118-164) is host arithmetic over the accumulators: fed the
+    reference's recorded _ep_usage / _ep_cnt it must return the reference's dict."""
+    from models.vq_vae import VectorQuantizerEMA
+    for name in ("vq_k512_d64_fresh", "vq_rvq4_k64_d32_masked", "vq_k512_d64_eval"):
+        g = load_golden(name)
+        q = VectorQuantizerEMA(int(g["K_per"]), int(g["D"]), num_quantizers=int(g["Q"]), print_init=False)
+        s = int(g["steps"]) - 1
+        q._ep_usage.copy_(torch.from_numpy(g[f"ep_usage_{s}"]))
+        q._ep_cnt.copy_(torch.from_numpy(np.asarray(g[f"ep_cnt_{s}"]).reshape(1)))
+        es = q.get_epoch_stats()
+        got = [es["perplexity"], es["dead_ratio"], es["n_positions"], es["margin_mean"], es["qe_mean"], es["qe_p90"]]
+        assert np.allclose(np.array(got, dtype=np.float64), g[f"epstats_{s}"], rtol=1e-6, atol=1e-9), (name, got, g[f"epstats_{s}"])
+        q.reset_epoch_stats()
+        assert q.get_epoch_stats()["n_positions"] == 0
+
+
+def test_devices_resolution_and_single_command_launch(tmp_path):
+    """trainer_params.devices drives the rank count like Lightning's `devices: N, strategy: ddp` (reference run.py:191-218):
+    `python run.py -c cfg` with devices: 2 starts 2 child ranks itself.  Without a GPU the children fail loudly -- which is
+    the proof that they were started (the parent never touches the GPU)."""
+    import subprocess
+    import run as run_mod
+    assert run_mod.resolve_devices({"devices": 1}) == 1
+    assert run_mod.resolve_devices({"devices": [0, 1, 2]}) == 3
+    assert run_mod.resolve_devices({"devices": "2"}) == 2
+    assert run_mod.resolve_devices({}) == 1
+    cfg = yaml.safe_load(open(os.path.join(PKG, "configs", "stage2_vq.yaml")))
+    cfg["model_params"].update(hidden_dim=64, num_layers=1, num_heads=4, tokenizer_heads=4, tokenizer_layers=1, max_seq_len=48,
+                               code_dim=16, latent_tokens=8, codebook_size=32, num_quantizers=1)
+    cfg["data_params"].update(train_batch_size=8, val_batch_size=8, num_workers=0, pin_memory=False,
+                              synthetic={"n": 32, "n_val": 8, "max_len": 40, "min_len": 20, "seed": 3})
+    cfg["exp_params"].update(checkpoint_dir=str(tmp_path / "ck"))
+    cfg["logging_params"] = {"save_dir": str(tmp_path / "logs"), "name": "t"}
+    cfg["trainer_params"].update(max_epochs=1, devices=2)
+    path = str(tmp_path / "ddp.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PYTHONPATH=PKG, VQH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "run.py"), "-c", path], cwd=PKG, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert "[Launch] starting 2 ranks" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "no CPU fallback" in (r.stdout + r.stderr)
+    # bench.py: --gpus must agree with the launcher's world size (it used to be parsed and ignored)
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env1, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
