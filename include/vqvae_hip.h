@@ -194,9 +194,15 @@ int vqh_vq_usage_stats(const float* usage, int K, float n_positions, float* ep_u
  * metrics[24] (device): loss, Reconstruction_Loss_XYZ, XYZ_MSE_Raw, XYZ_MSE_Aligned, Reconstruction_Loss_SS,
  *   SS_Accuracy, VQ_Loss, Geom_BondLength_Loss, Geom_BondAngle_Loss, Geom_Direction_Loss, Geom_Dihedral_Loss,
  *   Geom_Loss, SS_TV, Usage_Reg, XYZ_TV2, VQ_Perplexity, VQ_DeadRatio, RMSD_Raw, RMSD_Aligned, Geom_LocalPDM,
- *   Geom_WinKabsch, Frenet_Kappa, Frenet_Tau, Geom_LongRangePDM */
+ *   Geom_WinKabsch, Frenet_Kappa, Frenet_Tau, Geom_LongRangePDM
+ * L = the batch's own padded length (pad_collate's L_max: the window / long-range-pair enumerations of :996-1095 depend on it);
+ * L_stride >= L = rows per sample in memory (recons, target, mask, d_recons): the fused step pads L up to a length bucket
+ * and the loss still sees the reference's [B, L] view; d_recons rows L..L_stride-1 are written as zeros.
+ * L_dev (device, may be NULL): L as ONE float in device memory, read by the kernels instead of the argument, so that a captured
+ * hipGraph serves every L_max that falls into the same bucket (tables are then sized for L_stride) */
 int vqh_loss_fwd_bwd(const float* recons, const float* target, const unsigned char* mask, int masked, const float* ze,
-                     const float* zq, const float* vq_stats, int B, int L, int Ntok, int D, int use_vq,
+                     const float* zq, const float* vq_stats, int B, int L, int L_stride, const float* L_dev, int Ntok, int D,
+                     int use_vq,
                      const float* weights, const int* iparams, const float* data_stats, float* d_recons, float* d_ze,
                      float* metrics, float* workspace, long long workspace_floats, vqh_stream_t stream);
 

@@ -32,6 +32,8 @@ enum {
 
 struct LossCfg {
     int B, L, Ntok, D;
+    int Ls;                     // rows per sample IN MEMORY (>= L): the step pads L to a length bucket, the loss sees [B, L]
+    const float* Ldev;          // device scalar holding L (as a float) or null: one captured graph serves every L_max of a bucket
     int masked;                 // 0: the reference was called with mask=None (different normalisers)
     int use_vq;
     float rmsd_w, ss_w, bl_w, ba_w, dir_w, dih_w, tv_l, pdm_w, wk_w, kap_w, tau_w, lr_w;
@@ -42,6 +44,38 @@ struct LossCfg {
     int has_stats;              // set_data_stats(): geometry terms see x*sd + mu (reference to_real, :1218-1227)
     float sd[3], mu[3];
 };
+
+// Enumeration sizes of the reference's python loops for a batch of padded length L: long-range pairs (:1078-1082) and
+// Kabsch windows (:1003).  Evaluated on the host for sizing and on the device when L comes from device memory.
+__host__ __device__ inline void loss_enumerate(int L, int lr_sep, int lr_stride, int lr_max, int wk_size, int wk_stride,
+                                               int* npairs_out, int* nwin_out) {
+    int npairs = 0;
+    if (L >= lr_sep + 1) {
+        const int st = lr_stride > 1 ? lr_stride : 1;
+        for (int off = 0; off < (lr_max > 1 ? lr_max : 1); ++off) {
+            const int sep = lr_sep + off;
+            if (L - sep > 0) npairs += (L - sep + st - 1) / st;
+        }
+    }
+    int nwin = 0;
+    if (L >= 3 && wk_size >= 3 && L - wk_size + 1 > 0) {
+        const int st = wk_stride > 1 ? wk_stride : 1;
+        nwin = (L - wk_size) / st + 1;
+    }
+    *npairs_out = npairs;
+    *nwin_out = nwin;
+}
+
+// kernel-side view of the configuration: L (and what is enumerated from it) taken from device memory when given
+__device__ __forceinline__ LossCfg loss_resolve(LossCfg c) {
+    if (c.Ldev) {
+        int L = (int)(*c.Ldev + 0.5f);
+        L = L < 1 ? 1 : (L > c.Ls ? c.Ls : L);
+        c.L = L;
+        loss_enumerate(L, c.lr_sep, c.lr_stride, c.lr_max, c.wk_size, c.wk_stride, &c.n_lr_pairs, &c.n_windows);
+    }
+    return c;
+}
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r{x, y, z}; return r; }
@@ -244,12 +278,13 @@ __device__ bool block_kabsch(const float* a, const float* b, const float* m, int
 // ----------------------------------------------------------------------------------------------
 // counts from the mask: one block per sample, integer atomics (deterministic)
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_counts_kernel(const unsigned char* __restrict__ mask, LossCfg c,
+__global__ __launch_bounds__(256) void loss_counts_kernel(const unsigned char* __restrict__ mask, LossCfg c_in,
                                                           int* __restrict__ table) {
+    const LossCfg c = loss_resolve(c_in);
     extern __shared__ unsigned char sm_[];
     unsigned char* m = sm_;
     const int b = blockIdx.x, L = c.L;
-    for (int l = threadIdx.x; l < L; l += 256) m[l] = mask ? mask[(size_t)b * L + l] : 1;
+    for (int l = threadIdx.x; l < L; l += 256) m[l] = mask ? mask[(size_t)b * c.Ls + l] : 1;
     __syncthreads();
     int nv = 0, np = 0, nt = 0, nq = 0, n5 = 0;
     for (int l = threadIdx.x; l < L; l += 256) {
@@ -305,10 +340,11 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
                                                           const float* __restrict__ target,
                                                           const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ ze, const float* __restrict__ zq,
-                                                          const int* __restrict__ table, LossCfg c,
+                                                          const int* __restrict__ table, LossCfg c_in,
                                                           float* __restrict__ d_recons, float* __restrict__ d_ze,
                                                           float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const LossCfg c = loss_resolve(c_in);
     const int L = c.L, b = blockIdx.x, tid = threadIdx.x;
     double* dred = reinterpret_cast<double*>(sm);   // [4] (kept first: 8-byte aligned for any L)
     float* rx = sm + 8;           // [3L] reconstructed xyz
@@ -330,8 +366,8 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
     const float* gr = c.has_stats ? grb : gx;
     float* gR = c.has_stats ? gRb : g;
 
-    const float* rb = recons + (size_t)b * L * 6;
-    const float* tb = target + (size_t)b * L * 6;
+    const float* rb = recons + (size_t)b * c.Ls * 6;
+    const float* tb = target + (size_t)b * c.Ls * 6;
     for (int l = tid; l < L; l += 256) {
         for (int k = 0; k < 3; ++k) {
             rx[3 * l + k] = rb[6 * l + k];
@@ -344,7 +380,7 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
                 gRb[3 * l + k] = 0.f;
             }
         }
-        mk[l] = mask ? (float)mask[(size_t)b * L + l] : 1.f;
+        mk[l] = mask ? (float)mask[(size_t)b * c.Ls + l] : 1.f;
         // label = argmax of the one-hot target (first maximum)
         const float t0 = tb[6 * l + 3], t1 = tb[6 * l + 4], t2 = tb[6 * l + 5];
         int la = 0; float tm = t0;
@@ -409,7 +445,7 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
 
     // ---------------- secondary structure: CE / label smoothing, accuracy, TV (:1184-1215) ----------------
     float ce = 0.f, acc = 0.f, sstv = 0.f;
-    float* dlg = d_recons + (size_t)b * L * 6;   // logits grads are written straight to the output
+    float* dlg = d_recons + (size_t)b * c.Ls * 6;   // logits grads are written straight to the output
     const float inv_valid = tden(T_VALID), inv_pair = tden(T_PAIR), inv_tri = tden(T_TRI);
     for (int l = tid; l < L; l += 256) {
         const float a0 = lg[3 * l], a1 = lg[3 * l + 1], a2 = lg[3 * l + 2];
@@ -704,9 +740,10 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
     }
 
     // ---------------- outputs ----------------
-    float* dxb = d_recons + (size_t)b * L * 6;
+    float* dxb = d_recons + (size_t)b * c.Ls * 6;
     for (int l = tid; l < L; l += 256)
         for (int k = 0; k < 3; ++k) dxb[6 * l + k] = c.has_stats ? g[3 * l + k] + gRb[3 * l + k] * c.sd[k] : g[3 * l + k];
+    for (int i = 6 * L + tid; i < 6 * c.Ls; i += 256) dxb[i] = 0.f;      // bucket padding: no gradient
     if (tid == 0) {
         float* p = part + (size_t)b * P_COUNT;
         p[P_RAW] = raw; p[P_ALN] = aln; p[P_BEST] = best;
@@ -717,8 +754,9 @@ __global__ __launch_bounds__(256) void loss_sample_kernel(const float* __restric
 }
 
 // sum the per-sample partials in sample order and assemble the metric vector
-__global__ void loss_finish_kernel(const float* __restrict__ part, const int* __restrict__ table, LossCfg c,
+__global__ void loss_finish_kernel(const float* __restrict__ part, const int* __restrict__ table, LossCfg c_in,
                                    const float* __restrict__ vq_stats, float* __restrict__ metrics) {
+    const LossCfg c = loss_resolve(c_in);
     __shared__ double acc[P_COUNT];
     if (threadIdx.x < P_COUNT) {
         double s = 0.0;
@@ -774,15 +812,15 @@ __global__ void loss_finish_kernel(const float* __restrict__ part, const int* __
 // iparams: 6 ints {pdm_window, win_kabsch_size, win_kabsch_stride, lr_min_sep, lr_stride, lr_max_offsets}
 // metrics: 24 floats (order = reference dict + the 5 optional keys);  workspace: ints table + per-sample partials.
 extern "C" int vqh_loss_fwd_bwd(const float* recons, const float* target, const unsigned char* mask, int masked,
-                                const float* ze, const float* zq, const float* vq_stats, int B, int L, int Ntok, int D,
-                                int use_vq, const float* weights, const int* iparams, const float* data_stats,
+                                const float* ze, const float* zq, const float* vq_stats, int B, int L, int L_stride, const float* L_dev,
+                                int Ntok, int D, int use_vq, const float* weights, const int* iparams, const float* data_stats,
                                 float* d_recons, float* d_ze, float* metrics, float* workspace,
                                 long long workspace_floats, hipStream_t stream) {
-    VQH_CHECK_ARG(B > 0 && L > 0, "vqh_loss_fwd_bwd: bad shape");
+    VQH_CHECK_ARG(B > 0 && L > 0 && L_stride >= L, "vqh_loss_fwd_bwd: bad shape");
     VQH_CHECK_ARG(recons && target && weights && iparams && d_recons && metrics && workspace, "vqh_loss_fwd_bwd: null pointer");
     VQH_CHECK_ARG(!use_vq || (ze && zq && d_ze), "vqh_loss_fwd_bwd: VQ tensors missing");
     LossCfg c{};
-    c.B = B; c.L = L; c.Ntok = Ntok; c.D = D; c.masked = masked ? 1 : 0; c.use_vq = use_vq ? 1 : 0;
+    c.B = B; c.L = L_dev ? L_stride : L; c.Ls = L_stride; c.Ldev = L_dev; c.Ntok = Ntok; c.D = D; c.masked = masked ? 1 : 0; c.use_vq = use_vq ? 1 : 0;
     c.rmsd_w = weights[0]; c.ss_w = weights[1]; c.bl_w = weights[2]; c.ba_w = weights[3]; c.dir_w = weights[4];
     c.dih_w = weights[5]; c.tv_l = weights[6]; c.pdm_w = weights[7]; c.wk_w = weights[8]; c.kap_w = weights[9];
     c.tau_w = weights[10]; c.lr_w = weights[11]; c.alpha = weights[12]; c.ss_tv_l = weights[13];
@@ -792,21 +830,11 @@ extern "C" int vqh_loss_fwd_bwd(const float* recons, const float* target, const 
     c.has_stats = data_stats ? 1 : 0;
     for (int k = 0; k < 3; ++k) { c.sd[k] = data_stats ? data_stats[k] : 1.f; c.mu[k] = data_stats ? data_stats[3 + k] : 0.f; }
     VQH_CHECK_ARG(c.pdm_window <= 33, "vqh_loss_fwd_bwd: pdm_window > 33 unsupported");
-    // enumerate long-range pairs and windows exactly like the reference loops
-    int npairs = 0;
-    if (L >= c.lr_sep + 1) {
-        const int st = c.lr_stride > 1 ? c.lr_stride : 1;
-        for (int off = 0; off < (c.lr_max > 1 ? c.lr_max : 1); ++off) {
-            const int sep = c.lr_sep + off;
-            if (L - sep > 0) npairs += (L - sep + st - 1) / st;
-        }
-    }
+    // enumerate long-range pairs and windows exactly like the reference loops; with L on the device the tables are sized
+    // for the longest batch the buffers can hold (L_stride) and the kernels enumerate for the actual L
+    int npairs = 0, nwin = 0;
+    loss_enumerate(L_dev ? L_stride : L, c.lr_sep, c.lr_stride, c.lr_max, c.wk_size, c.wk_stride, &npairs, &nwin);
     c.n_lr_pairs = npairs;
-    int nwin = 0;
-    if (L >= 3 && c.wk_size >= 3 && L - c.wk_size + 1 > 0) {
-        const int st = c.wk_stride > 1 ? c.wk_stride : 1;
-        nwin = (L - c.wk_size) / st + 1;
-    }
     c.n_windows = nwin;
     c.t_wk = T_LR + npairs;
     const long long table_ints = c.t_wk + nwin + 8;
@@ -816,8 +844,9 @@ extern "C" int vqh_loss_fwd_bwd(const float* recons, const float* target, const 
     float* part = workspace + table_ints;
     hipError_t e = hipMemsetAsync(table, 0, sizeof(int) * table_ints, stream);
     if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
-    hipLaunchKernelGGL(loss_counts_kernel, dim3(B), dim3(256), (size_t)L, stream, mask, c, table);
-    const size_t smem = sizeof(float) * (size_t)(8 + 23 * L + 4 + 16 + 9 * L + 4);
+    const int Lmax = c.L;        // == L, or L_stride when L comes from the device
+    hipLaunchKernelGGL(loss_counts_kernel, dim3(B), dim3(256), (size_t)Lmax, stream, mask, c, table);
+    const size_t smem = sizeof(float) * (size_t)(8 + 23 * Lmax + 4 + 16 + 9 * Lmax + 4);
     VQH_CHECK_ARG(smem <= 160 * 1024, "vqh_loss_fwd_bwd: sequence too long for the LDS-resident loss kernel");
     static bool attr_set = false;
     if (!attr_set) {

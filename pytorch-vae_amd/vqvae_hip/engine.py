@@ -151,7 +151,7 @@ class StepEngine:
         self.drop_scale = 1.0                      # 0.0 disables every dropout site (parity runs)
         self._sites = {}
         self._flatten()
-        self.hyper = torch.zeros(9, device=self.dev, dtype=torch.float32)
+        self.hyper = torch.zeros(10, device=self.dev, dtype=torch.float32)    # 9 optimizer scalars + the batch's own L_max
         self._hyper_host, self._hyper_ev = None, None
         self.metrics_acc = torch.zeros(len(METRIC_KEYS), device=self.dev, dtype=torch.float32)
         self._pending_ema = None
@@ -258,7 +258,8 @@ class StepEngine:
         step's graph on the same stream (C2: 0.4 MB, ~10 us) -- there is no intermediate device tensor.  Returns (arena, x, mask); the
         mask stays None when the caller passed none and nothing was padded (the reference's mask=None variant)."""
         B, L0 = int(x.shape[0]), int(x.shape[1])
-        Lb = self.bucket_len(L0)
+        # mask=None is the reference's un-masked variant (different normalisers): such a batch keeps its own length
+        Lb = self.bucket_len(L0) if mask is not None else L0
         a = self.use_arena((B, Lb))
         xt = self.T("in.x", B, Lb, int(x.shape[2]))
         if Lb == L0:
@@ -1014,10 +1015,14 @@ class StepEngine:
         c["z_e"], c["z_q"], c["idx"], c["rec"], c["stats"] = z_e, z_q, idx, rec, stats
         return rec, z_e, z_q, idx, stats
 
-    def loss(self, rec, target, mask, z_e, z_q, stats, weights):
-        """VQVAE.loss_function (models/vq_vae.py:1097-1388): metrics (device vector) + d_rec, d_ze."""
+    def loss(self, rec, target, mask, z_e, z_q, stats, weights, L_logical=None, L_dev=None):
+        """VQVAE.loss_function (models/vq_vae.py:1097-1388): metrics (device vector) + d_rec, d_ze.
+        target is [B, Ls, 6] in memory; the loss is evaluated on the reference's view [B, L] with L = the batch's own
+        padded length (pad_collate's L_max: the window / long-range-pair enumerations of :996-1095 depend on it), given as
+        L_logical (host int) or L_dev (one device float, so that a captured graph serves every L_max of its bucket)."""
         m = self.m
-        B, Lq = target.shape[0], target.shape[1]
+        B, Ls = target.shape[0], target.shape[1]
+        Lq = int(L_logical) if L_logical is not None else Ls
         stats6 = None
         if m._data_std is not None:                                   # set_data_stats(): to_real() of :1218-1227
             mean = m._data_mean if m._data_mean is not None else torch.zeros(3)
@@ -1035,12 +1040,12 @@ class StepEngine:
         wa = (C.c_float * 16)(*w)
         ia = (C.c_int * 6)(*ip)
         sa = (C.c_float * 6)(*stats6) if stats6 is not None else None
-        d_rec = self.T("loss.d_rec", B * Lq, 6)
+        d_rec = self.T("loss.d_rec", B * Ls, 6)
         use_vq = bool(m.use_vq)
         Ntok = z_e.shape[0] // B
         d_ze = self.T("loss.d_ze", z_e.shape[0], self.D)
         call("vqh_loss_fwd_bwd", rec, target, mask, 1 if mask is not None else 0, z_e if use_vq else None,
-             z_q if use_vq else None, stats if use_vq else None, B, Lq, Ntok, self.D, int(use_vq),
+             z_q if use_vq else None, stats if use_vq else None, B, Lq, Ls, L_dev, Ntok, self.D, int(use_vq),
              C.cast(wa, C.c_void_p).value, C.cast(ia, C.c_void_p).value,
              C.cast(sa, C.c_void_p).value if sa is not None else None, d_rec, d_ze if use_vq else None, self.metrics,
              self.ws, self.ws.numel())
@@ -1083,21 +1088,21 @@ class StepEngine:
         for _ in self.encode_bwd_geo():
             yield
 
-    def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, L_logical=0):
         """Host -> device scalars of the next optimizer step (copied on the current stream, outside any graph)."""
         self.opt_step += 1
         t = self.opt_step
         # pinned staging ring + asynchronous copy: a pageable-memory copy would make the host wait for the previous step's
         # graph every step; the ring's events bound the host's run-ahead to HYPER_SLOTS steps instead
         if self._hyper_host is None:
-            self._hyper_host = [torch.empty(9, dtype=torch.float32).pin_memory() for _ in range(HYPER_SLOTS)]
+            self._hyper_host = [torch.zeros(10, dtype=torch.float32).pin_memory() for _ in range(HYPER_SLOTS)]
             self._hyper_ev = [None] * HYPER_SLOTS
         slot = t % HYPER_SLOTS
         if self._hyper_ev[slot] is not None:
             self._hyper_ev[slot].synchronize()
         hb = self._hyper_host[slot]
         vals = [lr, betas[0], betas[1], eps, weight_decay, max_norm if max_norm else 0.0,
-                1.0 - betas[0] ** t, 1.0 - betas[1] ** t, grad_scale]
+                1.0 - betas[0] ** t, 1.0 - betas[1] ** t, grad_scale, float(L_logical)]
         for i, v in enumerate(vals):
             hb[i] = float(v)
         self.hyper.copy_(hb, non_blocking=True)
@@ -1150,7 +1155,7 @@ class StepEngine:
                 rec, z_e, z_q, idx, stats = stop.value
                 break
             yield ("stats",)
-        self.loss(rec, x_tgt, mask, z_e, z_q, stats, weights)
+        self.loss(rec, x_tgt, mask, z_e, z_q, stats, weights, L_dev=self.hyper[9:])   # L_max of THIS batch: set_hyper
         ph = 0
         for _ in self.backward_gen():
             yield ("bucket", ph)
@@ -1215,7 +1220,8 @@ class StepEngine:
         world = self.world()
         from .parallel import dp_active
         dp = dp_active()                          # data-parallel form of the step (world > 1)
-        self.set_hyper(lr, weight_decay, clip, betas=getattr(self, "betas", (0.9, 0.999)), grad_scale=1.0 / world)
+        self.set_hyper(lr, weight_decay, clip, betas=getattr(self, "betas", (0.9, 0.999)), grad_scale=1.0 / world,
+                       L_logical=int(x.shape[1]))
         decay = float(m.quantizer.decay) if m.use_vq else 0.0
         # everything a captured graph bakes in as a kernel argument (the batch shape is the arena)
         key = (ms is not None, tuple(sorted((k, float(v)) for k, v in weights.items())), upd, decay,
@@ -1289,7 +1295,7 @@ class StepEngine:
         _, xt, ms = self._stage_batch(x, mask)
         upd = self._host_prologue()
         rec, z_e, z_q, idx, stats = self._forward_core(xt, ms, upd)
-        self.loss(rec, xt, ms, z_e, z_q, stats, weights)
+        self.loss(rec, xt, ms, z_e, z_q, stats, weights, L_logical=int(x.shape[1]))
         return self.metrics
 
     def advance_rng(self):

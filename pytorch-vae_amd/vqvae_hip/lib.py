@@ -52,7 +52,7 @@ _PROTOS = {
     "vqh_vq_usage_stats": "pifpppp",
     "vqh_row_sqnorm": "piiipfp",
     "vqh_vq_reinit": "pfppipppiip",
-    "vqh_loss_fwd_bwd": "pppipppiiiiippppppplp",
+    "vqh_loss_fwd_bwd": "pppipppiiipiiippppppplp",
     "vqh_grad_norm": "plpppp",
     "vqh_adamw_step": "pppplppp",
 }

@@ -285,10 +285,21 @@ def test_loss_function_honours_its_arguments_and_backward_guards():
     assert float(ld["VQ_Perplexity"]) == float(ppl) and float(ld["VQ_DeadRatio"]) == float(dead)
     ld["loss"].backward()
     g1 = eng.flat_g.clone()
+    m.zero_grad()                                           # p.grad = None: the next backward starts from scratch
     out = m(x, mask)
     ld = m.loss_function(*out, **w)
     (ld["loss"] / 4.0).backward()
     assert torch.allclose(eng.flat_g * 4.0, g1, rtol=1e-6, atol=0.0)
+    # torch semantics: without zero_grad() in between, gradients ACCUMULATE (micro-batches of (loss / accum).backward())
+    for _ in range(3):
+        out = m(x, mask)
+        (m.loss_function(*out, **w)["loss"] / 4.0).backward()
+    assert torch.allclose(eng.flat_g, g1, rtol=2e-6, atol=1e-9) and m.to_code.weight.grad.data_ptr() == eng.G["to_code.weight"].data_ptr()
+    m.zero_grad(set_to_none=False)                          # zeroes the flat buffer in place: accumulating onto zeros
+    out = m(x, mask)
+    m.loss_function(*out, **w)["loss"].backward()
+    assert torch.allclose(eng.flat_g, g1, rtol=2e-6, atol=1e-9)
+    m.zero_grad()
     # two forwards, then the FIRST forward's loss: refused
     out1 = m(x, mask)
     out2 = m(x, mask)
