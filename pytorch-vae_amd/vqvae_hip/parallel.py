@@ -3,14 +3,16 @@
 (= RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 The step has ONE kind of exchange: sum all-reduces over the flat buffer [gradients | EMA statistics], issued as
-four buckets (the gradients of the four backward phases, in the order backward completes them; the statistics ride
-behind the last one) so that each bucket travels while the next phase computes:
+2 * num_layers + 2 buckets that follow the backward phases (engine.bwd_phases: one per decoder layer, the tokenizer, the
+SS encoder + fusion MLP, one per geometry-encoder layer; the statistics ride behind the last one), so that each bucket
+travels while the next phase computes and only the last one (geometry layer 0 + input_proj + statistics: 7 % of the bytes
+at C2) is exposed:
   * gradients: DDP semantics (mean over ranks) -- the 1/world factor is folded into the clip coefficient
     that the fused AdamW kernel already multiplies into every gradient (hyper[8]), so no extra pass;
   * EMA statistics cnt[K] | sum[K,D]: wanted as SUMS over ranks, so that an N-rank step equals the
     single-process step on the concatenated batch (the reference's DDP never reduces
     them and broadcasts rank 0's codebook instead -- a documented, deliberate difference).
-The payload for config C2 is 172.5 MB + 0.13 MB in buckets of 68 / 26 / 28 / 51 MB: on xGMI (point-to-point links,
+The payload for config C2 is 172.5 MB + 0.13 MB in 10 buckets of 12-25 MB: on xGMI (point-to-point links,
 7 x ~153 GB/s per GPU) large messages are bandwidth-bound per link, many small ones latency-bound, so the buckets
 follow the backward phases instead of a fixed small size."""
 import os

@@ -145,3 +145,91 @@ def test_shard_bounds():
     assert [shard_bounds(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 2048)]
     with pytest.raises(ValueError):
         shard_bounds(10, 0, 4)
+
+
+# ---- world_size 8 at config C5's statistics payload (K = 8192, D = 256: 8.4 MB riding behind the last gradient bucket) ----
+C5_K, C5_D, C5_ROWS = 8192, 256, 128          # rows per rank (C5 has 4096 per rank; the exchange is the same size either way)
+
+
+def _c5_stats(z, emb):
+    d = (z * z).sum(1, keepdim=True) - 2.0 * z @ emb.t() + (emb * emb).sum(1)[None]
+    idx = d.argmin(1)
+    cnt = torch.zeros(C5_K).index_add_(0, idx, torch.ones(idx.shape[0]))
+    ssum = torch.zeros(C5_K, C5_D).index_add_(0, idx, z)
+    return cnt, ssum
+
+
+def _worker_c5(r, world, port, q):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-vae_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    torch.distributed.init_process_group("gloo", rank=r, world_size=world)
+    from vqvae_hip.engine import bwd_phases, _bwd_phase
+    from vqvae_hip.parallel import allreduce_async, shard_bounds
+    x, mask = G.curve_batch(2 * world, LQ, SEED + 3, ragged=False)
+    lo, hi = shard_bounds(2 * world)
+    cfg = O.make_cfg(**CFG)
+    sd = O.attach_grads(G.model_state(CFG, SEED), cfg)
+    orc = O.OracleVQVAE(sd, drop_scale=0.0, **CFG)
+    orc.training_steps = 1
+    ld = orc.loss_function(*orc.forward(x[lo:hi], mask[lo:hi]), **G.BASE_LOSS_WEIGHTS)
+    ld["loss"].backward()
+    # the engine's flat layout: parameters ordered by backward phase, one contiguous bucket per phase (StepEngine._flatten)
+    phases = bwd_phases(cfg["num_layers"])
+    names = list(O.param_shapes(cfg))
+    order = sorted(range(len(names)), key=lambda i: (_bwd_phase(names[i], phases), i))
+    sizes = [[sd[names[i]].numel() for i in order if _bwd_phase(names[i], phases) == ph] for ph in range(len(phases))]
+    g = torch.cat([sd[names[i]].grad.reshape(-1) for i in order])
+    zg = torch.Generator().manual_seed(900)
+    z_all = torch.randn(world * C5_ROWS, C5_D, generator=zg)
+    emb = torch.randn(C5_K, C5_D, generator=zg) / C5_D ** 0.5
+    cnt, ssum = _c5_stats(z_all[r * C5_ROWS:(r + 1) * C5_ROWS], emb)
+    flat = torch.cat([g, cnt, ssum.reshape(-1)])
+    bounds, o = [], 0
+    for ph in sizes:
+        bounds.append((o, o + sum(ph)))
+        o += sum(ph)
+    bounds[-1] = (bounds[-1][0], flat.numel())                     # the statistics ride behind the last bucket
+    works = [allreduce_async(flat[a:b]) for a, b in bounds]
+    for w in works:
+        w.wait()
+    if r == 0:
+        q.put(((flat[:g.numel()] / world).numpy(), flat[g.numel():g.numel() + C5_K].numpy().copy(),
+               flat[g.numel() + C5_K:].numpy().copy(), [b - a for a, b in bounds]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_ranks_with_c5_statistics_payload():
+    world = 8
+    port = 29500 + (os.getpid() % 2000) + 23
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_c5, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    g8, cnt8, sum8, bucket_sizes = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    g8, cnt8, sum8 = torch.from_numpy(g8), torch.from_numpy(cnt8), torch.from_numpy(sum8)
+    assert bucket_sizes[-1] * 4 >= (C5_K + C5_K * C5_D) * 4 >= 8.4e6          # the 8.4 MB of SURVEY.md 8e ride the last message
+    zg = torch.Generator().manual_seed(900)
+    z_all = torch.randn(world * C5_ROWS, C5_D, generator=zg)
+    emb = torch.randn(C5_K, C5_D, generator=zg) / C5_D ** 0.5
+    cnt1, sum1 = _c5_stats(z_all, emb)
+    assert torch.equal(cnt8, cnt1) and float(cnt1.sum()) == world * C5_ROWS
+    assert float((sum8 - sum1.reshape(-1)).abs().max()) <= 1e-5 * float(sum1.abs().max())
+    # gradients: mean over 8 shards of 2 == the single-process gradient on the 16 samples, in the engine's phase order
+    from vqvae_hip.engine import bwd_phases, _bwd_phase
+    x, mask = G.curve_batch(2 * world, LQ, SEED + 3, ragged=False)
+    cfg = O.make_cfg(**CFG)
+    sd = O.attach_grads(G.model_state(CFG, SEED), cfg)
+    orc = O.OracleVQVAE(sd, drop_scale=0.0, **CFG)
+    orc.training_steps = 1
+    orc.loss_function(*orc.forward(x, mask), **G.BASE_LOSS_WEIGHTS)["loss"].backward()
+    phases = bwd_phases(cfg["num_layers"])
+    names = list(O.param_shapes(cfg))
+    order = sorted(range(len(names)), key=lambda i: (_bwd_phase(names[i], phases), i))
+    g1 = torch.cat([sd[names[i]].grad.reshape(-1) for i in order])
+    assert float((g8 - g1).abs().max()) <= 2e-4 * float(g1.abs().max())
