@@ -85,10 +85,47 @@ int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* problems, float* workspace, l
  * accumulation): same accuracy as the fp32 MFMA against fp64 (csrc/gemm_dma.inc, tools/x3_lab.hip), 1.6-1.7x its speed */
 int vqh_gemm_set_flags(int flags);
 
+/* ---------------------------------------------------------------------------------------------
+ * Plane tensors ("P3") and the GEMM that consumes them (csrc/gemm_p3.inc) -- the default path of every Linear that tiles evenly.
+ * A plane tensor holds an fp32 matrix X[R][C] (C % 32 == 0) as its EXACT three-way bf16 split x = h + m + l (h = bf16(x),
+ * m = bf16(x - h), l = x - h - m; round to nearest even; 3 x 8 significant bits = fp32's 24):
+ *     bf16 P[R][C / 32][3 planes: h, m, l][32]      element (r, c) of plane p at byte r * pitch + (c >> 5) * 192 + p * 64 + (c & 31) * 2
+ * i.e. 1.5x the fp32 bytes.  Guaranteed domain: finite x with 2^-100 <= |x| <= 3.38e38 (exact; below 2^-100 the low planes reach
+ * the bf16 denormal range and the product keeps at least the high plane's 8 bits; above 3.38e38 h rounds to Inf and the
+ * product is NaN where an fp32 MFMA returns the value; Inf and NaN operands give NaN).
+ * The producers of GEMM operands (LayerNorm, GEMM epilogues, attention, the per-step weight split) write planes themselves;
+ * vqh_p3_split is the generic converter.  vqh_gemm_p3 computes C = epilogue(opA(A) . opB(B)) like vqh_gemm with both operands
+ * given as plane tensors (six bf16 MFMA products per fp32 product, fp32 accumulation: as accurate against fp64 as the fp32
+ * MFMA), writing fp32 (C), a plane tensor (Cp) or both; shapes must satisfy vqh_gemm_p3_eligible (M % 256, N % 128, K % 32).
+ * sign_bits: EPI_RELU_DROP writes, EPI_MUL_POSMASK reads 1 bit per output (v > 0) in the kernel's own order (M * N / 8 bytes),
+ * instead of an fp32 copy of the activation.  Layouts: (a_kcontig, b_kcontig) = (1, 1) forward, (1, 0) dgrad, (0, 0) wgrad.
+ * ------------------------------------------------------------------------------------------- */
+int vqh_p3_split(const float* X, int ldx, void* P, long long pitch_bytes, int rows, int cols, vqh_stream_t stream);
+typedef struct vqh_p3_item_t { const float* X; void* P; int rows, cols; long long ldx, pitch_bytes; } vqh_p3_item_t;
+/* many matrices in one launch: the per-step split of the weights (they change once per step, in AdamW) */
+int vqh_p3_split_multi(int n, const vqh_p3_item_t* items, vqh_stream_t stream);
+int vqh_gemm_p3_eligible(int M, int N, int K);
+int vqh_gemm_p3(int a_kcontig, int b_kcontig, int M, int N, int K, const void* Ap, long long pitch_a, const void* Bp,
+                long long pitch_b, float* C, int ldc, void* Cp, long long pitch_c, const float* bias, int mode,
+                const float* aux_in, float* aux_out, int ldaux, unsigned* sign_bits, float beta,
+                const unsigned long long* rng_state, unsigned drop_site, float drop_p, float* workspace,
+                long long workspace_floats, vqh_stream_t stream);
+/* all weight-gradient products of one layer on plane operands (see vqh_gemm_wgrad_group); every product must tile evenly
+ * (n_out % 256, k_in % 128, rows % 32); db (may be NULL) = column sums of dY, computed by MFMAs against a ones fragment */
+typedef struct vqh_wgrad_p3_t {
+    int rows, n_out, k_in;
+    const void* dYp; long long pitch_dy;
+    const void* Xp; long long pitch_x;
+    float* dW; int lddw;
+    float* db;
+} vqh_wgrad_p3_t;
+int vqh_gemm_p3_wgrad_group(int n, const vqh_wgrad_p3_t* problems, float* workspace, long long workspace_floats, vqh_stream_t stream);
+
 /* Live timing of the GEMM main kernels with HIP events on their launch stream (bench.py's roofline figure):
- * begin(), run eager (non-captured) steps, end(out) with out = double[5][4][9][3]: for kernel family (0 = gemm_f32_mfma,
+ * begin(), run eager (non-captured) steps, end(out) with out = double[7][4][9][3]: for kernel family (0 = gemm_f32_mfma,
  * the 128x128 register-staged tile; 1 = gemm_f32_dma, the 256x128 LDS-DMA tile; 2 = gemm_f32_dma_group, one entry per launch;
- * 3 = gemm_f32_x3 and 4 = gemm_f32_x3_group, the same tiles on the bf16 pipes), operand layout (a_kcontig*2 +
+ * 3 = gemm_f32_x3 and 4 = gemm_f32_x3_group, the same tiles on the bf16 pipes with the operand split inside the K loop;
+ * 5 = gemm_p3 and 6 = gemm_p3_group, plane-tensor operands), operand layout (a_kcontig*2 +
  * b_kcontig) and kernel template MODE+1 (0 = generic kernel, 1.. = epilogue-specialised): launches, kernel seconds,
  * sum of 2*M*N*K.  The split-K reduce launch is not inside the bracket. */
 int vqh_gemm_profile_begin(void);

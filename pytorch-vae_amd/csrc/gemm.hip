@@ -706,14 +706,16 @@ __global__ __launch_bounds__(256) void skinny_m_kernel(const float* __restrict__
 }
 
 #include "gemm_dma.inc"
+#include "gemm_p3.inc"
 
 // ---- live per-kernel timing (bench.py): hipEvents around each main-kernel launch, on the launch stream ----------
 struct ProfRec { int slot; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 constexpr int PROF_MODES = 9;                       // template MODE -1..7 -> column MODE+1
-constexpr int PROF_FAMILIES = 5;                    // 0 = gemm_f32_mfma (128x128 tile), 1 = gemm_f32_dma (256x128 tile), 2 = gemm_f32_dma_group,
-                                                    // 3 = gemm_f32_x3 (256x128 tile, bf16x3 split operands), 4 = gemm_f32_x3_group
+constexpr int PROF_FAMILIES = 7;                    // 0 = gemm_f32_mfma (128x128 tile), 1 = gemm_f32_dma (256x128 tile), 2 = gemm_f32_dma_group,
+                                                    // 3 = gemm_f32_x3 (256x128 tile, bf16x3 split operands), 4 = gemm_f32_x3_group,
+                                                    // 5 = gemm_p3 (pre-split plane operands, 16x16x32 MFMA), 6 = gemm_p3_group
 inline int prof_slot(bool a_kc, bool b_kc, int mode_t, int family = 0) {
     return (family * 4 + (a_kc ? 2 : 0) + (b_kc ? 1 : 0)) * PROF_MODES + mode_t + 1;
 }
@@ -1197,6 +1199,292 @@ extern "C" int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* pr, float* workspa
             hipLaunchKernelGGL(splitk_reduce_group, dim3(blocks, nred), dim3(256), 0, stream, RG);
         }
         VQH_LAUNCH_CHECK();
+    }
+    return VQH_OK;
+}
+
+
+// ================================================================================================================================
+// Plane-tensor ("P3") entry points: see gemm_p3.inc and include/vqvae_hip.h
+// ================================================================================================================================
+extern "C" int vqh_p3_split(const float* X, int ldx, void* P, long long pitch_bytes, int rows, int cols, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return VQH_OK;
+    VQH_CHECK_ARG(X && P, "vqh_p3_split: null pointer");
+    VQH_CHECK_ARG((cols % 32) == 0 && ldx >= cols && (ldx & 3) == 0 && pitch_bytes >= (long long)cols * 6 && (pitch_bytes % 16) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P)) & 15) == 0,
+                  "vqh_p3_split: cols % 32, ldx % 4, 16-byte alignment and pitch >= 6 * cols required");
+    const long long total = (long long)rows * (cols >> 3);
+    int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(p3_split_kernel, dim3(blocks), dim3(256), 0, stream, X, (long long)ldx, reinterpret_cast<char*>(P), pitch_bytes, rows, cols);
+    VQH_LAUNCH_CHECK();
+    return VQH_OK;
+}
+
+struct vqh_p3_item_t { const float* X; void* P; int rows, cols; long long ldx, pitch_bytes; };
+extern "C" int vqh_p3_split_multi(int n, const vqh_p3_item_t* items, hipStream_t stream) {
+    VQH_CHECK_ARG(n >= 0 && (n == 0 || items), "vqh_p3_split_multi: bad argument");
+    for (int c0 = 0; c0 < n; c0 += P3_SPLIT_MAX) {
+        P3SplitArgs S;
+        S.n = std::min(P3_SPLIT_MAX, n - c0);
+        long long most = 0;
+        for (int i = 0; i < S.n; ++i) {
+            const vqh_p3_item_t& it = items[c0 + i];
+            VQH_CHECK_ARG(it.X && it.P && it.rows > 0 && it.cols > 0 && (it.cols % 32) == 0 && it.ldx >= it.cols && (it.ldx & 3) == 0 &&
+                          it.pitch_bytes >= (long long)it.cols * 6 && (it.pitch_bytes % 16) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(it.X) | reinterpret_cast<uintptr_t>(it.P)) & 15) == 0,
+                          "vqh_p3_split_multi: bad item (cols % 32, alignment, pitch)");
+            S.it[i] = P3SplitItem{it.X, reinterpret_cast<char*>(it.P), it.rows, it.cols, it.ldx, it.pitch_bytes};
+            most = std::max(most, (long long)it.rows * (it.cols >> 3));
+        }
+        int bx = (int)std::min<long long>((most + 255) / 256, 512);
+        hipLaunchKernelGGL(p3_split_multi_kernel, dim3(bx, S.n), dim3(256), 0, stream, S);
+        VQH_LAUNCH_CHECK();
+    }
+    return VQH_OK;
+}
+
+namespace {
+inline int p3_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = prop.multiProcessorCount;
+        else n = 256;
+    }
+    return n;
+}
+template <bool A_KC, bool B_KC, int MODE>
+int launch_p3(const P3Args& g, int splits, hipStream_t stream) {
+    static bool attr_set = false;
+    auto kern = &gemm_p3<A_KC, B_KC, MODE>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, p3::LDS_BYTES);
+        if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    // persistent: at most one resident workgroup per CU (144 KB of LDS each), each walking its share of the tiles x splits
+    const int n_items = (g.M / p3::TBM) * (g.N / p3::TBN) * splits;
+    dim3 grid(std::min(n_items, p3_num_cus()));
+    ProfRec rec{};
+    if (g_prof_on) {
+        rec.slot = prof_slot(A_KC, B_KC, MODE, 5);
+        rec.flops = 2.0 * g.M * g.N * g.K;
+        if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess || hipEventRecord(rec.e0, stream) != hipSuccess) {
+            vqh_set_error("vqh_gemm_p3: profiling events failed");
+            return VQH_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), p3::LDS_BYTES, stream, g, n_items);
+    VQH_LAUNCH_CHECK();
+    if (g_prof_on) {
+        if (hipEventRecord(rec.e1, stream) != hipSuccess) { vqh_set_error("vqh_gemm_p3: profiling events failed"); return VQH_ERR_LAUNCH; }
+        g_prof.push_back(rec);
+    }
+    return VQH_OK;
+}
+inline bool p3_tensor_ok(const void* P, long long pitch, int cols) {
+    return P && (reinterpret_cast<uintptr_t>(P) & 15) == 0 && (pitch % 16) == 0 && pitch >= (long long)cols * 6;
+}
+}  // namespace
+
+// 1 when vqh_gemm_p3 accepts the shape (the caller keeps fp32 operands and vqh_gemm for everything else)
+extern "C" int vqh_gemm_p3_eligible(int M, int N, int K) {
+    return (M > 0 && N > 0 && K >= p3::TBK && (M % p3::TBM) == 0 && (N % p3::TBN) == 0 && (K % p3::TBK) == 0 &&
+            (long long)M * N / 2 < (1LL << 32)) ? 1 : 0;
+}
+
+extern "C" int vqh_gemm_p3(int a_kcontig, int b_kcontig, int M, int N, int K, const void* Ap, long long pitch_a, const void* Bp,
+                           long long pitch_b, float* C, int ldc, void* Cp, long long pitch_c, const float* bias, int mode,
+                           const float* aux_in, float* aux_out, int ldaux, unsigned* sign_bits, float beta,
+                           const unsigned long long* rng_state, unsigned drop_site, float drop_p, float* workspace,
+                           long long workspace_floats, hipStream_t stream) {
+    VQH_CHECK_ARG(vqh_gemm_p3_eligible(M, N, K), "vqh_gemm_p3: shape not eligible (M % 256, N % 128, K % 32)");
+    VQH_CHECK_ARG(mode >= EPI_LINEAR && mode <= EPI_MUL_SIGGRAD, "vqh_gemm_p3: unknown epilogue mode");
+    VQH_CHECK_ARG(p3_tensor_ok(Ap, pitch_a, a_kcontig ? K : M) && p3_tensor_ok(Bp, pitch_b, b_kcontig ? K : N),
+                  "vqh_gemm_p3: operand plane tensor (alignment / pitch)");
+    VQH_CHECK_ARG(C || Cp, "vqh_gemm_p3: no output");
+    VQH_CHECK_ARG(!C || (ldc >= N && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0), "vqh_gemm_p3: C alignment / ldc");
+    VQH_CHECK_ARG(!Cp || p3_tensor_ok(Cp, pitch_c, N), "vqh_gemm_p3: output plane tensor (alignment / pitch)");
+    VQH_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0, "vqh_gemm_p3: bias alignment");
+    if (mode == EPI_GELU) VQH_CHECK_ARG(aux_out && ldaux >= N && (ldaux & 3) == 0, "vqh_gemm_p3: GELU epilogue needs aux_out");
+    if (mode == EPI_DROP_RESID || mode == EPI_MUL_GELUGRAD || mode == EPI_MUL_SIGGRAD)
+        VQH_CHECK_ARG(aux_in && ldaux >= N && (ldaux & 3) == 0 && (reinterpret_cast<uintptr_t>(aux_in) & 15) == 0, "vqh_gemm_p3: epilogue needs aux_in");
+    if (mode == EPI_MUL_POSMASK) VQH_CHECK_ARG(sign_bits && (reinterpret_cast<uintptr_t>(sign_bits) & 15) == 0, "vqh_gemm_p3: POSMASK needs the sign bits");
+    VQH_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "vqh_gemm_p3: dropout p out of range");
+    if (drop_p > 0.f && (mode == EPI_RELU_DROP || mode == EPI_DROP_RESID)) VQH_CHECK_ARG(rng_state != nullptr, "vqh_gemm_p3: dropout needs rng_state");
+    VQH_CHECK_ARG(beta == 0.f || (C && !Cp), "vqh_gemm_p3: beta needs the fp32 output (and no plane output)");
+
+    P3Args g{};
+    g.A = reinterpret_cast<const char*>(Ap); g.B = reinterpret_cast<const char*>(Bp);
+    g.pa = pitch_a; g.pb = pitch_b;
+    g.C = C; g.ldc = ldc; g.Cp = reinterpret_cast<char*>(Cp); g.pc = pitch_c;
+    g.M = M; g.N = N; g.K = K;
+    g.mode = mode; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux;
+    g.bits_out = (mode == EPI_RELU_DROP) ? sign_bits : nullptr;
+    g.bits_in = (mode == EPI_MUL_POSMASK) ? sign_bits : nullptr;
+    g.beta = beta;
+    g.drop = make_drop(rng_state, drop_site, drop_p);
+    g.ws = nullptr; g.rowsum = nullptr; g.rowsum_ws = nullptr;
+    g.flags = g_gemm_flags;
+    const int tiles = (M / p3::TBM) * (N / p3::TBN);
+    int splits = 1;
+    if (workspace && mode == EPI_LINEAR && !Cp && beta == 0.f && tiles < 192 && K >= 8 * p3::TBK) {
+        splits = 256 / tiles;
+        const int max_by_k = K / (4 * p3::TBK);
+        if (splits > max_by_k) splits = max_by_k;
+        if ((long long)splits * M * N > workspace_floats) splits = (int)(workspace_floats / ((long long)M * N));
+        if (splits < 2) splits = 1;
+    }
+    int kchunk = ((K + splits - 1) / splits + p3::TBK - 1) / p3::TBK * p3::TBK;
+    splits = (K + kchunk - 1) / kchunk;
+    g.kchunk = kchunk;
+    if (splits > 1) g.ws = workspace;
+    int rc;
+    const bool one = splits == 1;
+    if (a_kcontig && b_kcontig) {
+        if (one && mode == EPI_DROP_RESID) rc = launch_p3<true, true, EPI_DROP_RESID>(g, splits, stream);
+        else if (one && mode == EPI_RELU_DROP) rc = launch_p3<true, true, EPI_RELU_DROP>(g, splits, stream);
+        else if (one && mode == EPI_GELU) rc = launch_p3<true, true, EPI_GELU>(g, splits, stream);
+        else if (mode == EPI_LINEAR) rc = launch_p3<true, true, EPI_LINEAR>(g, splits, stream);
+        else rc = launch_p3<true, true, -1>(g, splits, stream);
+    } else if (a_kcontig && !b_kcontig) {
+        if (one && mode == EPI_MUL_POSMASK) rc = launch_p3<true, false, EPI_MUL_POSMASK>(g, splits, stream);
+        else if (one && mode == EPI_MUL_GELUGRAD) rc = launch_p3<true, false, EPI_MUL_GELUGRAD>(g, splits, stream);
+        else if (mode == EPI_LINEAR) rc = launch_p3<true, false, EPI_LINEAR>(g, splits, stream);
+        else rc = launch_p3<true, false, -1>(g, splits, stream);
+    } else if (!a_kcontig && !b_kcontig) {
+        VQH_CHECK_ARG(mode == EPI_LINEAR, "vqh_gemm_p3: the transposed-A product supports the linear epilogue only");
+        rc = launch_p3<false, false, EPI_LINEAR>(g, splits, stream);
+    } else {
+        vqh_set_error("vqh_gemm_p3: layout (a_kcontig = 0, b_kcontig = 1) is not built (no call site)");
+        return VQH_ERR_ARG;
+    }
+    if (rc != VQH_OK) return rc;
+    if (splits > 1) {
+        const size_t total = (size_t)M * N;
+        int blocks = (int)((total / 4 + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_vec, dim3(blocks), dim3(256), 0, stream, workspace, splits, M, N, C, ldc, bias, beta,
+                           (const float*)nullptr, (float*)nullptr);
+        VQH_LAUNCH_CHECK();
+    }
+    return VQH_OK;
+}
+
+// All weight-gradient products of one layer on plane operands: dW_p[n_out, k_in] = dY_p[rows, n_out]^T . X_p[rows, k_in], db_p =
+// column sums of dY_p (MFMAs against a ones fragment), one grouped launch + one grouped split-K reduce.  Every product must tile
+// evenly (n_out % 256, k_in % 128, rows % 32): the caller routes other shapes through the fp32 entry points.
+struct vqh_wgrad_p3_t {
+    int rows, n_out, k_in;
+    const void* dYp; long long pitch_dy;
+    const void* Xp; long long pitch_x;
+    float* dW; int lddw;
+    float* db;
+};
+extern "C" int vqh_gemm_p3_wgrad_group(int n, const vqh_wgrad_p3_t* pr, float* workspace, long long workspace_floats, hipStream_t stream) {
+    VQH_CHECK_ARG(n >= 0 && (n == 0 || pr), "vqh_gemm_p3_wgrad_group: bad argument");
+    VQH_CHECK_ARG(workspace && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "vqh_gemm_p3_wgrad_group: workspace");
+    for (int i = 0; i < n; ++i) {
+        const vqh_wgrad_p3_t& w = pr[i];
+        VQH_CHECK_ARG(w.rows >= p3::TBK && (w.rows % p3::TBK) == 0 && w.n_out > 0 && (w.n_out % p3::TBM) == 0 && w.k_in > 0 &&
+                      (w.k_in % p3::TBN) == 0 && p3_tensor_ok(w.dYp, w.pitch_dy, w.n_out) && p3_tensor_ok(w.Xp, w.pitch_x, w.k_in) &&
+                      w.dW && (reinterpret_cast<uintptr_t>(w.dW) & 15) == 0 && (w.lddw & 3) == 0 && w.lddw >= w.k_in,
+                      "vqh_gemm_p3_wgrad_group: product does not tile evenly / bad operand");
+    }
+    for (int c0 = 0; c0 < n; c0 += GROUP_MAX) {
+        const int m = std::min(GROUP_MAX, n - c0);
+        int kmax = 0;
+        for (int j = 0; j < m; ++j) kmax = std::max(kmax, pr[c0 + j].rows);
+        int best_kc = kmax;
+        double best = -1.0;
+        for (int sp = 1; sp <= 64; ++sp) {
+            const int kc = ((kmax + sp - 1) / sp + p3::TBK - 1) / p3::TBK * p3::TBK;
+            if (kc < 16 * p3::TBK && sp > 1) break;
+            long long wgs = 0, slab = 0;
+            for (int j = 0; j < m; ++j) {
+                const vqh_wgrad_p3_t& w = pr[c0 + j];
+                const int splits = (w.rows + kc - 1) / kc;
+                wgs += (long long)(w.n_out / p3::TBM) * (w.k_in / p3::TBN) * splits;
+                if (splits > 1) slab += (long long)splits * ((long long)w.n_out * w.k_in + w.n_out) + 4;
+            }
+            if (slab > workspace_floats) continue;
+            const double rounds = (double)((wgs + 255) / 256);
+            const double util = (double)wgs / (256.0 * rounds);
+            const double score = util * (double)kc / ((double)kc + 12.0 * p3::TBK);
+            if (score > best) { best = score; best_kc = kc; }
+        }
+        VQH_CHECK_ARG(best >= 0.0, "vqh_gemm_p3_wgrad_group: workspace too small");
+        P3GroupArgs G;
+        G.n = m;
+        int wg = 0;
+        long long off = 0;
+        double flops = 0.0;
+        struct Red { float* ws; int splits, M, N; float* C; int ldc; float* rs_ws; float* rowsum; };
+        Red red[GROUP_MAX];
+        int nred = 0;
+        for (int j = 0; j < m; ++j) {
+            const vqh_wgrad_p3_t& w = pr[c0 + j];
+            P3Args& g = G.p[j];
+            g = P3Args{};
+            g.A = reinterpret_cast<const char*>(w.dYp); g.B = reinterpret_cast<const char*>(w.Xp);
+            g.pa = w.pitch_dy; g.pb = w.pitch_x;
+            g.C = w.dW; g.ldc = w.lddw; g.Cp = nullptr; g.pc = 0;
+            g.M = w.n_out; g.N = w.k_in; g.K = w.rows;
+            g.kchunk = best_kc;
+            g.mode = EPI_LINEAR; g.beta = 0.f;
+            g.drop = make_drop(nullptr, 0, 0.f);
+            g.flags = g_gemm_flags;
+            g.rowsum = w.db;
+            const int splits = (w.rows + best_kc - 1) / best_kc;
+            if (splits > 1) {
+                g.ws = workspace + off;
+                off += (long long)splits * w.n_out * w.k_in;
+                g.rowsum_ws = w.db ? workspace + off : nullptr;
+                if (w.db) off += (long long)splits * w.n_out;
+                off = (off + 3) / 4 * 4;
+                red[nred++] = Red{g.ws, splits, w.n_out, w.k_in, w.dW, w.lddw, g.rowsum_ws, w.db};
+            }
+            G.wg_begin[j] = wg;
+            wg += (w.n_out / p3::TBM) * (w.k_in / p3::TBN) * splits;
+            flops += 2.0 * w.n_out * (double)w.k_in * w.rows;
+        }
+        for (int j = m; j <= GROUP_MAX; ++j) G.wg_begin[j] = wg;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p3_group), hipFuncAttributeMaxDynamicSharedMemorySize, p3::LDS_BYTES);
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+            attr_set = true;
+        }
+        ProfRec rec{};
+        if (g_prof_on) {
+            rec.slot = prof_slot(false, false, EPI_LINEAR, 6);
+            rec.flops = flops;
+            if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess || hipEventRecord(rec.e0, stream) != hipSuccess) {
+                vqh_set_error("vqh_gemm_p3_wgrad_group: profiling events failed");
+                return VQH_ERR_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL(gemm_p3_group, dim3(wg), dim3(512), p3::LDS_BYTES, stream, G);
+        VQH_LAUNCH_CHECK();
+        if (g_prof_on) {
+            if (hipEventRecord(rec.e1, stream) != hipSuccess) { vqh_set_error("vqh_gemm_p3_wgrad_group: profiling events failed"); return VQH_ERR_LAUNCH; }
+            g_prof.push_back(rec);
+        }
+        if (nred > 0) {
+            RedGroupArgs RG;
+            RG.n = nred;
+            int blocks = 1;
+            for (int j = 0; j < nred; ++j) {
+                const Red& r = red[j];
+                RG.r[j] = RedGroupArgs::Item{r.ws, r.splits, r.M, r.N, r.C, r.ldc, r.rs_ws, r.rowsum};
+                blocks = std::max(blocks, (int)(((size_t)r.M * r.N / 4 + 255) / 256));
+            }
+            if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(splitk_reduce_group, dim3(blocks, nred), dim3(256), 0, stream, RG);
+            VQH_LAUNCH_CHECK();
+        }
     }
     return VQH_OK;
 }

@@ -25,6 +25,10 @@ _PROTOS = {
     "vqh_gemm": "iiiiipipipipippifpufplp",
     "vqh_gemm_wgrad": "iiipipipipfplp",
     "vqh_gemm_wgrad_group": "ipplp",
+    "vqh_p3_split": "pipliip",
+    "vqh_p3_split_multi": "ipp",
+    "vqh_gemm_p3": "iiiiiplplpiplpippipfpufplp",
+    "vqh_gemm_p3_wgrad_group": "ipplp",
     "vqh_layernorm_fwd": "pipppippiifp",
     "vqh_layernorm_bwd": "pipippppiippfiippufplp",
     "vqh_reduce_slabs": "pillpfp",
@@ -57,7 +61,7 @@ _PROTOS = {
     "vqh_adamw_step": "pppplppp",
 }
 _CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "l": C.c_longlong, "u": C.c_uint}
-EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_set_flags", "vqh_attn_set_flags", "vqh_gemm_profile_begin", "vqh_gemm_profile_end",
+EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_p3_eligible", "vqh_gemm_set_flags", "vqh_attn_set_flags", "vqh_gemm_profile_begin", "vqh_gemm_profile_end",
            "vqh_vq_set_flags", "vqh_vq_profile_begin", "vqh_vq_profile_end"] + list(_PROTOS)
 
 
@@ -71,6 +75,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.vqh_last_error.restype = C.c_char_p
         L.vqh_abi_version.restype = C.c_int
+        L.vqh_gemm_p3_eligible.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.vqh_gemm_p3_eligible.restype = C.c_int
         L.vqh_gemm_profile_end.argtypes = [C.c_void_p]
         L.vqh_vq_profile_end.argtypes = [C.c_void_p]
         for name, sig in _PROTOS.items():
@@ -125,7 +131,7 @@ def gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, mode=EPI_LIN
     _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, aux_out, ldaux, beta, rng, site, p, ws)
 
 
-GEMM_PROF_FAMILIES = 5
+GEMM_PROF_FAMILIES = 7
 GEMM_FLAG_NATIVE_F32 = 512          # vqh_gemm_set_flags bit: large tiles on v_mfma_f32_32x32x2_f32 instead of the bf16x3 split
 
 
@@ -212,3 +218,70 @@ def _gemm(a_kc, b_kc, M, N, K, A, lda, B, ldb, Cout, ldc, bias, mode, aux_in, au
     call("vqh_gemm", int(a_kc), int(b_kc), M, N, K, _p(A), lda, _p(B), ldb, _p(Cout), ldc, _p(bias), mode,
          _p(aux_in), _p(aux_out), ldaux, float(beta), _p(rng), site, float(p), _p(ws),
          (ws.numel() if ws is not None else 0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# plane tensors (include/vqvae_hip.h "P3"): an fp32 matrix [R, C] as its exact 3-way bf16 split, [R][C/32][3][32] bf16
+# ---------------------------------------------------------------------------------------------------------------------
+class P3ItemT(C.Structure):
+    """vqh_p3_item_t"""
+    _fields_ = [("X", C.c_void_p), ("P", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ldx", C.c_longlong),
+                ("pitch_bytes", C.c_longlong)]
+
+
+class WgradP3T(C.Structure):
+    """vqh_wgrad_p3_t"""
+    _fields_ = [("rows", C.c_int), ("n_out", C.c_int), ("k_in", C.c_int), ("dYp", C.c_void_p), ("pitch_dy", C.c_longlong),
+                ("Xp", C.c_void_p), ("pitch_x", C.c_longlong), ("dW", C.c_void_p), ("lddw", C.c_int), ("db", C.c_void_p)]
+
+
+def p3_empty(rows, cols, device):
+    """Uninitialised plane tensor for an fp32 [rows, cols] matrix (cols % 32 == 0): int16 [rows, cols // 32, 3, 32]."""
+    if cols % 32:
+        raise VqhError(f"plane tensors need cols % 32 == 0 (got {cols})")
+    return torch.empty(rows, cols // 32, 3, 32, device=device, dtype=torch.int16)
+
+
+def p3_pitch(P):
+    return int(P.stride(0)) * 2
+
+
+def p3_split(X, P=None):
+    """fp32 matrix (2-D, row stride % 4 == 0) -> its plane tensor (generic converter kernel)."""
+    rows, cols = X.shape
+    if P is None:
+        P = p3_empty(rows, cols, X.device)
+    call("vqh_p3_split", X, int(X.stride(0)), P, p3_pitch(P), int(rows), int(cols))
+    return P
+
+
+def p3_to_float(P):
+    """Plane tensor -> fp32 matrix h + m + l (host-side check helper; exact)."""
+    f = (P.to(torch.int32) << 16).view(torch.float32)          # bf16 bits -> fp32
+    rows, nb = P.shape[0], P.shape[1]
+    return (f[:, :, 0] + f[:, :, 1] + f[:, :, 2]).reshape(rows, nb * 32)
+
+
+def gemm_p3_eligible(M, N, K):
+    return bool(lib().vqh_gemm_p3_eligible(int(M), int(N), int(K)))
+
+
+def gemm_p3(a_kc, b_kc, M, N, K, Ap, Bp, Cout=None, ldc=0, Cp=None, bias=None, mode=EPI_LINEAR, aux_in=None, aux_out=None,
+            ldaux=0, sign_bits=None, beta=0.0, rng=None, site=0, p=0.0, ws=None, pitch_a=None, pitch_b=None, pitch_c=None):
+    call("vqh_gemm_p3", int(a_kc), int(b_kc), M, N, K, Ap, pitch_a if pitch_a is not None else p3_pitch(Ap), Bp,
+         pitch_b if pitch_b is not None else p3_pitch(Bp), _p(Cout), int(ldc), _p(Cp),
+         (pitch_c if pitch_c is not None else (p3_pitch(Cp) if Cp is not None else 0)), _p(bias), mode, _p(aux_in), _p(aux_out),
+         int(ldaux), _p(sign_bits), float(beta), _p(rng), site, float(p), _p(ws), (ws.numel() if ws is not None else 0))
+
+
+def wgrad_group_p3(items, ws):
+    """items: [(dYp, pitch_dy, Xp, pitch_x, rows, dW [n_out, k_in], db or None)] -> one grouped launch on plane operands."""
+    n = len(items)
+    if n == 0:
+        return
+    arr = (WgradP3T * n)()
+    for i, (dyp, pdy, xp, px, rows, gW, gb) in enumerate(items):
+        n_out, k_in = gW.shape
+        arr[i] = WgradP3T(int(rows), int(n_out), int(k_in), dyp.data_ptr() if torch.is_tensor(dyp) else int(dyp), int(pdy),
+                          xp.data_ptr() if torch.is_tensor(xp) else int(xp), int(px), gW.data_ptr(), int(gW.stride(0)), _p(gb))
+    call("vqh_gemm_p3_wgrad_group", n, C.cast(arr, C.c_void_p), ws, ws.numel())
