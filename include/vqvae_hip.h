@@ -198,11 +198,15 @@ int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long*
  * vqh_vq_nearest = distances + argmin (:183-188 / :238-244) without the R x K matrix: fp32 MFMA scores with top-2 tracking,
  * rows inside the fp32 noise band re-evaluated in fp64 (first-minimum tie rule of torch.argmin).  For D = 8..256 (power
  * of two) the codebook streams through LDS in 64-code tiles shared by 4 waves that keep their Z rows in registers.
- * workspace_floats >= 3T + 4K + 2R + 3*nsplit*R + R/4 + 8 with T = smallest power of two >= 2K (>= 64), nsplit <= K/256 + 1 */
+ * workspace_floats >= 3T + 4K + 2R + 3*nsplit*R + R/4 + 16 + K*(6D+16)/4 + R + 3*min(R,16384)*ceil(K/256) with T = smallest power
+ * of two >= 2K (>= 64), nsplit <= K/256 + 1.  Rows flagged ambiguous are compacted into a list and re-evaluated by (row, 256-code
+ * chunk) work items spread over the whole chip, merged with the first-minimum rule */
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
                    int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);
 /* diagnostic: bit 0 = always use the per-wave global-gather nearest kernel (round-1 form); bit 1 = score with the fp32 MFMA
- * instead of the bf16 pipes on exactly split operands (D = 64 / 128 / 256; same indices); returns the previous flags */
+ * instead of the bf16 pipes on exactly split operands (D = 64 / 128 / 256; same indices); bit 2 = segment sums of large tables
+ * by one workgroup per code instead of (row chunk, code range) workgroups; bit 3 = one-wave-per-row refinement instead of the
+ * chip-wide one (A/B runs: same results); returns the previous flags */
 int vqh_vq_set_flags(int flags);
 /* live timing of the nearest-neighbour main kernel with HIP events on its launch stream (bench.py --vq-only):
  * begin(), eager calls, end(out) with out = double[3] = {launches, kernel seconds, sum of 2*R*K*D} */

@@ -568,6 +568,102 @@ __global__ __launch_bounds__(256) void vq_refine_kernel(const float* __restrict_
     if (lane == 0 && bidx != 0x7fffffff) idx_out[row] = (long long)bidx + idx_offset;
 }
 
+// ---- chip-wide refinement ----------------------------------------------------------------------------------------------
+// vq_refine_kernel gives every flagged row ONE wave that scans all K codes (K * D * 4 bytes through one wave: 8 MB and
+// 1.1 ms per call at K = 8192, D = 256, whatever the number of flagged rows).  Here the flagged rows are compacted into a
+// list and the (row, 256-code chunk) pairs are spread over the whole chip; a second small kernel merges a row's partials
+// (lowest index wins ties, like torch.argmin).  Same arithmetic and the same candidate rule as vq_refine_kernel, so both give
+// identical indices.  Rows beyond the partial buffer's capacity (a pathological table) fall back to the full scan.
+constexpr int REFINE_CPW = 256;            // codes per work item (4 per lane)
+__global__ void vq_amb_compact_kernel(const unsigned char* __restrict__ ambiguous, int R, int* __restrict__ count,
+                                      int* __restrict__ list) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < R && ambiguous[r]) list[atomicAdd(count, 1)] = r;      // order is irrelevant: rows are independent
+}
+
+__device__ __forceinline__ void refine_score_codes(const float* __restrict__ zp, const float* __restrict__ E, int lde, int D, int kbeg,
+                                                   int kend, int lane, float thr, double& best, int& bidx) {
+    for (int k = kbeg + lane; k < kend; k += 64) {
+        const float* ep = E + (size_t)k * lde;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int i = 0; i < D; i += 4) {
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(zp + i), ev = *reinterpret_cast<const f32x4*>(ep + i);
+            const f32x4 d = zv - ev;
+            s0 += d[0] * d[0]; s1 += d[1] * d[1]; s2 += d[2] * d[2]; s3 += d[3] * d[3];
+        }
+        if ((s0 + s1) + (s2 + s3) <= thr) {
+            double s = 0.0;
+            for (int i = 0; i < D; ++i) {
+                const double d = (double)zp[i] - (double)ep[i];
+                s += d * d;
+            }
+            if (s < best || (s == best && k < bidx)) { best = s; bidx = k; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_refine_items_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ E, int lde,
+                                                              const int* __restrict__ count, const int* __restrict__ list,
+                                                              const float* __restrict__ znorm, const float* __restrict__ bestval,
+                                                              int K, int D, int CH, int cap, float rel_tol,
+                                                              double* __restrict__ pdist, int* __restrict__ pidx) {
+    const int lane = threadIdx.x & 63;
+    const int nrows = min(*count, cap);
+    const long long items = (long long)nrows * CH, nwaves = (long long)gridDim.x * 4;
+    for (long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); w < items; w += nwaves) {
+        const int li = (int)(w / CH), ch = (int)(w % CH);
+        const int row = list[li];
+        const float zn = znorm[row];
+        const float scale = zn + fabsf(bestval[row]) + 1e-30f;
+        const float thr = (zn + bestval[row]) + 4.f * rel_tol * scale;
+        double best = 1e300;
+        int bidx = 0x7fffffff;
+        refine_score_codes(Z + (size_t)row * ldz, E, lde, D, ch * REFINE_CPW, min(K, (ch + 1) * REFINE_CPW), lane, thr, best, bidx);
+        if (lane == 0) { pdist[w] = best; pidx[w] = bidx; }
+    }
+}
+
+// one wave per listed row: merge its CH partials (or, beyond the buffer's capacity, scan the whole table)
+__global__ __launch_bounds__(256) void vq_refine_merge_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ E, int lde,
+                                                              const int* __restrict__ count, const int* __restrict__ list,
+                                                              const float* __restrict__ znorm, const float* __restrict__ bestval,
+                                                              int K, int D, int CH, int cap, float rel_tol,
+                                                              const double* __restrict__ pdist, const int* __restrict__ pidx,
+                                                              long long* __restrict__ idx_out, int idx_offset) {
+    const int lane = threadIdx.x & 63;
+    const int n = *count;
+    for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < n; li += gridDim.x * 4) {
+        const int row = list[li];
+        double best = 1e300;
+        int bidx = 0x7fffffff;
+        if (li < cap) {
+            for (int c = lane; c < CH; c += 64) {
+                const double d = pdist[(size_t)li * CH + c];
+                const int i = pidx[(size_t)li * CH + c];
+                if (d < best || (d == best && i < bidx)) { best = d; bidx = i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bidx, o, 64);
+                if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            }
+        } else {
+            const float zn = znorm[row];
+            const float scale = zn + fabsf(bestval[row]) + 1e-30f;
+            const float thr = (zn + bestval[row]) + 4.f * rel_tol * scale;
+            refine_score_codes(Z + (size_t)row * ldz, E, lde, D, 0, K, lane, thr, best, bidx);
+        }
+        if (lane == 0 && bidx != 0x7fffffff) idx_out[row] = (long long)bidx + idx_offset;
+    }
+}
+
 // z_q = E[idx - idx_offset]; z_st = z + (z_q - z); zq_acc (+)= z_q ; res_out = res_in - z_q
 __global__ void vq_gather_kernel(const float* __restrict__ E, int lde, const long long* __restrict__ idx,
                                  int idx_offset, const float* __restrict__ rows_in, int ldr,
@@ -685,6 +781,108 @@ __global__ __launch_bounds__(256) void vq_segment_table_kernel(const float* __re
     __syncthreads();
     float* out = part + (size_t)blockIdx.x * (n + Kn);
     for (int i = threadIdx.x; i < n + Kn; i += 256) out[i] = table[i];
+}
+
+// Large tables (Kn * D floats beyond the LDS): the per-code block of vq_segment_sum_kernel reads ALL R indices (Kn blocks x R
+// x 8 bytes: 17 GB of L2 traffic at Kn = 8192, R = 262144 -- 1.36 ms).  Here a workgroup owns (row chunk c, code range g):
+// it scans the chunk's indices once, and accumulates the rows whose code falls into ITS range of KR codes into an LDS table
+// of KR * D floats.  Every row is fetched exactly once over the whole grid (it matches one range), the index array is read
+// once per range, and the result is deterministic: wave w owns the codes with (code & 15) == w and visits the chunk's rows in
+// ascending order, the chunks' partial tables are summed in chunk order by vq_table_reduce_kernel.
+// part[c][Kn * D + Kn]: sums then counts of chunk c.
+__global__ __launch_bounds__(1024) void vq_segment_range_kernel(const float* __restrict__ rows, int ldr, const long long* __restrict__ idx,
+                                                                int R, int D, int k0, int Kn, int KR, int rows_per_chunk,
+                                                                float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float table[];   // [KR * D] sums, [KR] counts, then the waves' row lists
+    // 16 waves: wave w owns the codes with (code & 15) == w.  The scan only COLLECTS the wave's rows (ascending) in a small LDS
+    // list; the list is then gathered 8 rows at a time, so 16 x 8 KB are in flight per CU (matches are sparse -- one row in
+    // 64 falls into a range -- and a gather per match would cost one dependent HBM round trip each).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x, c = blockIdx.y;
+    const int klo = g * KR, kn = min(KR, Kn - klo);                  // this block's codes: klo .. klo + kn (relative to k0)
+    const int n = kn * D;
+    for (int i = threadIdx.x; i < KR * D + KR; i += 1024) table[i] = 0.f;
+    int* lrow = reinterpret_cast<int*>(table + (size_t)KR * D + KR) + wave * 256;   // [128] rows, [128] codes
+    int* lcod = lrow + 128;
+    const int r_beg = c * rows_per_chunk, r_end = min(R, r_beg + rows_per_chunk);
+    __syncthreads();
+    const int vpl = D >> 8;                                          // float4 per lane and row when D % 256 == 0
+    int cnt = 0;                                                     // entries in this wave's list (wave-uniform)
+    auto flush = [&]() {
+        for (int i0 = 0; i0 < cnt; i0 += 8) {
+            int rr[8], cd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = i0 + u < cnt;
+                rr[u] = on ? lrow[i0 + u] : -1;
+                cd[u] = on ? lcod[i0 + u] : 0;
+            }
+            if ((D & 255) == 0) {
+                for (int q = 0; q < vpl; ++q) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = (rr[u] >= 0) ? *reinterpret_cast<const f32x4*>(rows + (size_t)rr[u] * ldr + q * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (rr[u] >= 0) {
+                            f32x4* t = reinterpret_cast<f32x4*>(table + (size_t)cd[u] * D + q * 256 + lane * 4);
+                            *t = *t + v[u];
+                        }
+                }
+            } else {
+                for (int col = lane; col < D; col += 64) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = (rr[u] >= 0) ? rows[(size_t)rr[u] * ldr + col] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (rr[u] >= 0) table[(size_t)cd[u] * D + col] += v[u];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (rr[u] >= 0) table[(size_t)KR * D + cd[u]] += 1.f;
+            }
+        }
+        cnt = 0;
+    };
+    // the indices of 8 row groups are requested together (one dependent L2 round trip per group made the scan the bottleneck)
+    for (int base8 = r_beg; base8 < r_end; base8 += 512) {
+        long long ci8[8];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) {
+            const int r = base8 + 64 * u8 + lane;
+            ci8[u8] = (r < r_end) ? idx[r] : -1;
+        }
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) {
+            const long long ci = ci8[u8] - k0 - klo;
+            const int code = (ci8[u8] >= 0 && ci >= 0 && ci < kn) ? (int)ci : -1;
+            const bool mine = code >= 0 && (code & 15) == wave;
+            const unsigned long long m = __ballot(mine);
+            if (m) {
+                if (mine) {
+                    const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    lrow[pos] = base8 + 64 * u8 + lane;
+                    lcod[pos] = code;
+                }
+                cnt += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (cnt >= 64) {                                   // a group adds at most 64 entries: the list (128) cannot overflow
+                    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the list entries have landed
+                    flush();
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    flush();
+    __syncthreads();
+    float* out = part + (size_t)c * ((size_t)Kn * D + Kn);
+    for (int i = threadIdx.x; i < n; i += 1024) out[(size_t)klo * D + i] = table[i];
+    for (int i = threadIdx.x; i < kn; i += 1024) out[(size_t)Kn * D + klo + i] = table[(size_t)KR * D + i];
 }
 
 __global__ __launch_bounds__(1024) void vq_table_reduce_kernel(const float* __restrict__ part, int S, long long stride,
@@ -818,7 +1016,8 @@ extern "C" int vqh_vq_profile_end(double* out) {
 }
 
 // workspace (floats): hash table (3 T, T = power of two >= 2K) + K hashes (2K) + canon (K) + K code norms + R row norms +
-// R best scores + nsplit*R*(best, second, index) + R/4 flag bytes
+// R best scores + nsplit*R*(best, second, index) + R/4 flag bytes + the split codebook + the refinement's list of flagged rows
+// (R + 4) and partials (3 * min(R, 16384) * ceil(K / 256))
 extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset,
                               int R, int K, int D, float rel_tol, float* workspace, long long workspace_floats,
                               hipStream_t stream) {
@@ -847,7 +1046,11 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     nsplit = (K + kchunk - 1) / kchunk;
     int T = 64;
     while (T < 2 * K) T <<= 1;
-    const long long need = 3LL * T + 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8 + ex_floats + 4;
+    // chip-wide refinement (vq_refine_items_kernel): list of flagged rows + partials for up to `cap` of them
+    const int CH = (K + REFINE_CPW - 1) / REFINE_CPW;
+    const int cap = R < 16384 ? R : 16384;
+    const long long refine_floats = 4 + (long long)R + 3LL * cap * CH + 2;
+    const long long need = 3LL * T + 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8 + ex_floats + 4 + refine_floats;
     VQH_CHECK_ARG(need <= workspace_floats, "vqh_vq_nearest: workspace too small");
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);       // 2T floats, 8-byte aligned
     int* minidx = reinterpret_cast<int*>(workspace + 2 * (size_t)T);
@@ -930,8 +1133,26 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     }
     hipLaunchKernelGGL(vq_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, pbest, psecond, pidx, canon, nsplit, znorm,
                        idx_out, idx_offset, amb, bestval, R, rel_tol);
-    hipLaunchKernelGGL(vq_refine_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, E, lde, idx_out, idx_offset, amb,
-                       znorm, bestval, R, K, D, rel_tol);
+    if (g_vq_flags & 8) {                  // A/B: the one-wave-per-row refinement
+        hipLaunchKernelGGL(vq_refine_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, E, lde, idx_out, idx_offset, amb,
+                           znorm, bestval, R, K, D, rel_tol);
+        VQH_LAUNCH_CHECK();
+        return VQH_OK;
+    }
+    {
+        unsigned char* after = Ex + (size_t)ex_floats * 4;
+        int* rcount = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(after) + 15) & ~(uintptr_t)15);
+        int* rlist = rcount + 4;
+        double* pdist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(rlist + R) + 7) & ~(uintptr_t)7);
+        int* pidx2 = reinterpret_cast<int*>(pdist + (size_t)cap * CH);
+        hipError_t e = hipMemsetAsync(rcount, 0, sizeof(int), stream);
+        if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+        hipLaunchKernelGGL(vq_amb_compact_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, amb, R, rcount, rlist);
+        hipLaunchKernelGGL(vq_refine_items_kernel, dim3(1024), dim3(256), 0, stream, Z, ldz, E, lde, rcount, rlist, znorm, bestval, K, D,
+                           CH, cap, rel_tol, pdist, pidx2);
+        hipLaunchKernelGGL(vq_refine_merge_kernel, dim3(256), dim3(256), 0, stream, Z, ldz, E, lde, rcount, rlist, znorm, bestval, K, D, CH,
+                           cap, rel_tol, pdist, pidx2, idx_out, idx_offset);
+    }
     VQH_LAUNCH_CHECK();
     return VQH_OK;
 }
@@ -999,6 +1220,36 @@ extern "C" int vqh_vq_segment_sum(const float* rows, int ldr, const long long* i
                            (long long)Kn, cnt + k0);
         VQH_LAUNCH_CHECK();
         return VQH_OK;
+    }
+    // large tables: (row chunk, code range) workgroups with an LDS table per range (see vq_segment_range_kernel)
+    if (workspace && !(g_vq_flags & 4) && D >= 8 && D <= 1024 && R >= 4096) {
+        int KR = 1;
+        while (KR * 2 * (long long)(D + 1) <= 32768 && KR * 2 <= Kn) KR *= 2;       // table <= 128 KB
+        const int ranges = (Kn + KR - 1) / KR;
+        int chunks = (1024 + ranges - 1) / ranges;                                  // ~1024 workgroups
+        const int max_chunks = (R + 2047) / 2048;                                   // >= 2048 rows per chunk
+        if (chunks > max_chunks) chunks = max_chunks;
+        while (chunks > 1 && (long long)chunks * tbl > workspace_floats) --chunks;
+        if (chunks >= 1 && (long long)chunks * tbl <= workspace_floats && (reinterpret_cast<uintptr_t>(rows) & 15) == 0 && (ldr & 3) == 0) {
+            const int rpc = ((R + chunks - 1) / chunks + 63) / 64 * 64;
+            chunks = (R + rpc - 1) / rpc;
+            static bool attr_set2 = false;
+            if (!attr_set2) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_segment_range_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+                attr_set2 = true;
+            }
+            hipLaunchKernelGGL(vq_segment_range_kernel, dim3(ranges, chunks), dim3(1024), (size_t)(KR * (D + 1) + 16 * 256) * sizeof(float), stream,
+                               rows, ldr, idx, R, D, k0, Kn, KR, rpc, workspace);
+            const long long n = (long long)Kn * D;
+            hipLaunchKernelGGL(vq_table_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, stream, workspace, chunks, tbl, n,
+                               sum + (size_t)k0 * D);
+            hipLaunchKernelGGL(vq_table_reduce_kernel, dim3((Kn + 63) / 64), dim3(1024), 0, stream, workspace + n, chunks, tbl,
+                               (long long)Kn, cnt + k0);
+            VQH_LAUNCH_CHECK();
+            return VQH_OK;
+        }
     }
 #define SEG(V) hipLaunchKernelGGL((vq_segment_sum_kernel<V>), dim3(Kn), dim3(256), 0, stream, rows, ldr, idx, R, D, k0, cnt, sum)
     if (D <= 64) SEG(1);

@@ -112,7 +112,7 @@ def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
     z[5] = emb[7]
     ws = torch.empty(48 * 1024 * 1024, device=DEV)
     got = []
-    for flags in (0, 1):
+    for flags in (0, 1, 8):                              # default | per-wave gather kernel | one-wave-per-row refinement
         old = L.lib().vqh_vq_set_flags(flags)
         try:
             idx = torch.full((R,), -1, device=DEV, dtype=torch.int64)
@@ -121,7 +121,7 @@ def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
         finally:
             L.lib().vqh_vq_set_flags(old)
         got.append(idx)
-    assert torch.equal(got[0], got[1])
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
     want = torch.empty(R, dtype=torch.int64, device=DEV)
     e64 = emb.double()
     en = (e64 * e64).sum(1)[None]
@@ -135,3 +135,37 @@ def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
         ok = (dd[:, 0] < dd[:, 1]) | ((dd[:, 0] == dd[:, 1]) & (cand[:, 0] <= cand[:, 1]))
         assert bool(ok.all()), f"{int((~ok).sum())} rows are not the exact nearest code"
     assert int(got[0][5]) == 7
+
+
+@pytest.mark.parametrize("R,K,D,skew", [(262144, 8192, 256, False), (65536, 8192, 256, True), (20000, 1000, 24, False),
+                                        (16384, 4096, 512, False), (8192, 2048, 64, True)])
+def test_vq_segment_sums_large_tables(R, K, D, skew):
+    """EMA statistics of tables that do not fit the LDS (models/vq_vae.py:77-83: cnt = bincount, sum = one_hot^T x): the
+    (row chunk, code range) kernel against an fp64 index_add, against the one-workgroup-per-code kernel (flag bit 2), bitwise
+    reproducible, also when the codebook has collapsed onto a few codes and with -1 (masked) ids."""
+    from vqvae_hip import lib as L
+    L.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(R + K + D)
+    z = torch.randn(R, D, generator=g).to(DEV)
+    idx = (torch.randint(0, 7, (R,), generator=g) * (K // 7) if skew else torch.randint(0, K, (R,), generator=g)).to(DEV)
+    idx[::97] = -1                                         # masked positions (vqh_vq_mask_ids) match no code
+    ws = torch.empty(48 * 1024 * 1024, device=DEV)
+    valid = idx >= 0
+    want_cnt = torch.zeros(K, device=DEV, dtype=torch.float64).index_add_(0, idx[valid], torch.ones(int(valid.sum()), device=DEV, dtype=torch.float64))
+    want_sum = torch.zeros(K, D, device=DEV, dtype=torch.float64).index_add_(0, idx[valid], z[valid].double())
+    outs = []
+    for flags in (0, 0, 4):
+        old = L.lib().vqh_vq_set_flags(flags)
+        try:
+            cnt = torch.full((K,), float("nan"), device=DEV)
+            ssum = torch.full((K, D), float("nan"), device=DEV)
+            L.call("vqh_vq_segment_sum", z, D, idx, R, D, 0, K, cnt, ssum, ws, ws.numel())
+            torch.cuda.synchronize()
+        finally:
+            L.lib().vqh_vq_set_flags(old)
+        outs.append((cnt, ssum))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "not reproducible"
+    for cnt, ssum in (outs[0], outs[2]):
+        assert torch.equal(cnt.double(), want_cnt)
+        scale = float(want_sum.abs().max())
+        assert float((ssum.double() - want_sum).abs().max()) <= 2e-6 * scale * (30 if skew else 1)
