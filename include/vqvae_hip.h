@@ -204,9 +204,10 @@ int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long*
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
                    int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);
 /* diagnostic: bit 0 = always use the per-wave global-gather nearest kernel (round-1 form); bit 1 = score with the fp32 MFMA
- * instead of the bf16 pipes on exactly split operands (D = 64 / 128 / 256; same indices); bit 2 = segment sums of large tables
- * by one workgroup per code instead of (row chunk, code range) workgroups; bit 3 = one-wave-per-row refinement instead of the
- * chip-wide one (A/B runs: same results); returns the previous flags */
+ * instead of the bf16 pipes on exactly split operands (D = 64 / 128 / 256; same indices); segment sums of tables beyond the LDS
+ * run as a stable radix sort by code + a segmented sum (skew-proof) unless bit 2 (one workgroup per code) or bit 4
+ * ((row chunk, code range) workgroups with LDS tables) is set; bit 3 = one-wave-per-row refinement instead of the chip-wide one
+ * (A/B runs: same results); returns the previous flags */
 int vqh_vq_set_flags(int flags);
 /* live timing of the nearest-neighbour main kernel with HIP events on its launch stream (bench.py --vq-only):
  * begin(), eager calls, end(out) with out = double[3] = {launches, kernel seconds, sum of 2*R*K*D} */

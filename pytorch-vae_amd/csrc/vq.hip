@@ -885,6 +885,205 @@ __global__ __launch_bounds__(1024) void vq_segment_range_kernel(const float* __r
     for (int i = threadIdx.x; i < kn; i += 1024) out[(size_t)Kn * D + klo + i] = table[(size_t)KR * D + i];
 }
 
+// ---- sorted form: stable radix sort of the rows by code, then a segmented sum over the sorted list ------------------------------
+// Both table forms above serialise on a skewed code distribution (early in training most rows share a few codes: one wave of
+// one workgroup then adds thousands of rows, 0.6 ms per RVQ level at R = 8192).  Sorted by code (stable: rows of a code stay in
+// ascending order), the sums are a segmented reduction over a list: every wave takes SEG consecutive entries whatever the
+// distribution, interior runs are written directly, the runs cut by a wave boundary go through a small partial buffer that a
+// fix-up kernel adds in wave order.  Deterministic, no table, no per-chunk partial tables; cost = the row bytes once.
+// Sort: LSD radix, 7 bits per pass (1-3 passes for K <= 2^21), ranks by one ballot per bucket (no atomics):
+//   pass kernels: (1) per 64-row group: bucket counts [group][128] + each row's rank inside its group and bucket,
+//                 (2) per bucket: exclusive scan of the counts down the groups + bucket totals,
+//                 (3) scatter to base(bucket) + prefix(group, bucket) + rank.
+constexpr int SORT_BITS = 7, SORT_NB = 1 << SORT_BITS;
+__global__ __launch_bounds__(256) void vq_sort_hist_kernel(const long long* __restrict__ idx, const int* __restrict__ key_in, int R, int k0,
+                                                           int Kn, int shift, int* __restrict__ key_out0,
+                                                           int* __restrict__ counts, unsigned char* __restrict__ rank) {
+    const int lane = threadIdx.x & 63, group = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = group * 64 + lane;
+    if (group * 64 >= R) return;
+    int key = Kn;                                                   // invalid / masked rows sort behind every code
+    if (r < R) {
+        if (key_in) key = key_in[r];
+        else {
+            const long long c = idx[r] - k0;
+            key = (c >= 0 && c < Kn) ? (int)c : Kn;
+            key_out0[r] = key;
+        }
+    }
+    const int d = (r < R) ? ((key >> shift) & (SORT_NB - 1)) : -1;
+    int myrank = 0, c0 = 0, c1 = 0;
+#pragma unroll 8
+    for (int b = 0; b < SORT_NB; ++b) {
+        const unsigned long long m = __ballot(d == b);
+        if (d == b) myrank = __popcll(m & ((1ull << lane) - 1ull));
+        const int n = __popcll(m);
+        if ((b & 63) == lane) { if (b < 64) c0 = n; else c1 = n; }
+    }
+    counts[(size_t)group * SORT_NB + lane] = c0;
+    counts[(size_t)group * SORT_NB + 64 + lane] = c1;
+    if (r < R) rank[r] = (unsigned char)myrank;
+}
+
+// one workgroup per bucket: exclusive prefix of counts[g][b] over the groups g (in place) and totals[b]
+__global__ __launch_bounds__(1024) void vq_sort_scan_kernel(int* __restrict__ counts, int G, int* __restrict__ totals) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int per = (G + 1023) / 1024;
+    const int g0 = t * per, g1 = min(G, g0 + per);
+    int s = 0;
+    for (int g = g0; g < g1; ++g) s += counts[(size_t)g * SORT_NB + b];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                           // Hillis-Steele inclusive scan of the 1024 partial sums
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;                                          // exclusive prefix of this thread's slice
+    for (int g = g0; g < g1; ++g) {
+        const int c = counts[(size_t)g * SORT_NB + b];
+        counts[(size_t)g * SORT_NB + b] = run;
+        run += c;
+    }
+    if (t == 1023) totals[b] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void vq_sort_scatter_kernel(const int* __restrict__ key_in, const int* __restrict__ row_in, int R, int shift,
+                                                              const int* __restrict__ counts, const int* __restrict__ totals,
+                                                              const unsigned char* __restrict__ rank, int* __restrict__ key_out,
+                                                              int* __restrict__ row_out) {
+    __shared__ int base[SORT_NB];
+    if (threadIdx.x < 64) {                                         // exclusive scan of the 128 bucket totals (one wave)
+        const int a = totals[2 * threadIdx.x], b2 = totals[2 * threadIdx.x + 1];
+        int incl = a + b2;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += v;
+        }
+        base[2 * threadIdx.x] = incl - a - b2;
+        base[2 * threadIdx.x + 1] = incl - b2;
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const int key = key_in[r];
+    const int d = (key >> shift) & (SORT_NB - 1);
+    const int pos = base[d] + counts[(size_t)(r >> 6) * SORT_NB + d] + (int)rank[r];
+    key_out[pos] = key;
+    row_out[pos] = row_in ? row_in[r] : r;
+}
+
+// Segmented sum over the sorted list.  One wave per SEG entries; lane l holds columns {4 l + 256 q .. + 3} (D % 4 == 0, D <= 1024).
+//   interior runs -> sum / cnt directly;  first and last run of the wave -> partial slots 2 w and 2 w + 1 (key, count, vector)
+constexpr int SEG = 256;
+template <int NQ>
+__global__ __launch_bounds__(256) void vq_seg_reduce_kernel(const float* __restrict__ rows, int ldr, const int* __restrict__ skey,
+                                                            const int* __restrict__ srow, int R, int D, int k0, int Kn,
+                                                            float* __restrict__ cnt, float* __restrict__ sum, int* __restrict__ pkey,
+                                                            float* __restrict__ pcnt, float* __restrict__ pvec) {
+    const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int e0 = w * SEG, e1 = min(R, e0 + SEG);
+    if (e0 >= R) return;
+    const int prev_key = (e0 > 0) ? skey[e0 - 1] : -1;
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur = -1, n = 0, nruns = 0;
+    if (lane == 0) { pkey[2 * w] = -1; pkey[2 * w + 1] = -1; }
+    // end of a run: a run that continues from the previous wave (the wave's first run, same key as the entry before e0) or into
+    // the next wave (`cont`) is a partial; everything else is final
+    auto flush = [&](bool cont) {
+        if (cur < 0 || cur >= Kn) return;                           // nothing yet / the invalid bucket
+        const bool is_first = (nruns == 0) && (cur == prev_key);
+        if (is_first || cont) {
+            const int slot = is_first ? 2 * w : 2 * w + 1;
+            if (lane == 0) { pkey[slot] = cur; pcnt[slot] = (float)n; }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (4 * lane + 256 * q < D) *reinterpret_cast<f32x4*>(pvec + (size_t)slot * D + 4 * lane + 256 * q) = acc[q];
+        } else {
+            if (lane == 0) cnt[k0 + cur] = (float)n;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (4 * lane + 256 * q < D) *reinterpret_cast<f32x4*>(sum + (size_t)(k0 + cur) * D + 4 * lane + 256 * q) = acc[q];
+        }
+    };
+    for (int base = e0; base < e1; base += 64) {
+        const int e = base + lane;
+        const int mykey = (e < e1) ? skey[e] : -1;
+        const int myrow = (e < e1) ? srow[e] : 0;
+        const int cntb = min(64, e1 - base);
+        for (int i0 = 0; i0 < cntb; i0 += 8) {
+            f32x4 v[8][NQ];
+            int kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = i0 + u < cntb;
+                kk[u] = on ? __shfl(mykey, i0 + u, 64) : -2;
+                const int rr = __shfl(myrow, on ? i0 + u : 0, 64);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    v[u][q] = (on && kk[u] < Kn && 4 * lane + 256 * q < D) ? *reinterpret_cast<const f32x4*>(rows + (size_t)rr * ldr + 4 * lane + 256 * q)
+                                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (kk[u] == -2) continue;
+                if (kk[u] != cur) {
+                    flush(false);
+                    if (cur >= 0) ++nruns;
+                    cur = kk[u]; n = 0;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] += v[u][q];
+                ++n;
+            }
+        }
+    }
+    // the wave's last run continues into the next wave iff that wave starts with the same key
+    flush((e1 < R) && (skey[e1] == cur));
+}
+
+// partial slots in order 0, 1, 2, ...: slots with the same key are consecutive (sorted list); the first slot of such a run adds
+// them in slot order and writes the code's final sum and count.  One wave per slot.
+template <int NQ>
+__global__ __launch_bounds__(256) void vq_seg_fixup_kernel(const int* __restrict__ pkey, const float* __restrict__ pcnt,
+                                                           const float* __restrict__ pvec, int nslots, int D, int k0,
+                                                           float* __restrict__ cnt, float* __restrict__ sum) {
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= nslots) return;
+    const int key = pkey[s];
+    if (key < 0) return;
+    // previous valid slot with the same key -> not the head of the run
+    for (int t = s - 1; t >= 0; --t) {
+        const int k = pkey[t];
+        if (k == key) return;
+        if (k >= 0) break;
+    }
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float n = 0.f;
+    for (int t = s; t < nslots; ++t) {
+        const int k = pkey[t];
+        if (k < 0) continue;
+        if (k != key) break;
+        n += pcnt[t];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (4 * lane + 256 * q < D) acc[q] += *reinterpret_cast<const f32x4*>(pvec + (size_t)t * D + 4 * lane + 256 * q);
+    }
+    if (lane == 0) cnt[k0 + key] = n;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (4 * lane + 256 * q < D) *reinterpret_cast<f32x4*>(sum + (size_t)(k0 + key) * D + 4 * lane + 256 * q) = acc[q];
+}
+
 __global__ __launch_bounds__(1024) void vq_table_reduce_kernel(const float* __restrict__ part, int S, long long stride,
                                                                long long n, float* __restrict__ out) {
     __shared__ float red[16][64];
@@ -1221,7 +1420,60 @@ extern "C" int vqh_vq_segment_sum(const float* rows, int ldr, const long long* i
         VQH_LAUNCH_CHECK();
         return VQH_OK;
     }
-    // large tables: (row chunk, code range) workgroups with an LDS table per range (see vq_segment_range_kernel)
+    // large tables, default: stable sort by code + segmented sum (see vq_sort_* / vq_seg_reduce_kernel)
+    if (workspace && !(g_vq_flags & (4 | 16)) && (D & 3) == 0 && D <= 1024 && R >= 1 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0 &&
+        (ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(sum) & 15) == 0) {
+        const int G = (R + 63) / 64, nwaves = (R + SEG - 1) / SEG, nslots = 2 * nwaves;
+        const long long Rp = ((long long)R + 3) / 4 * 4;
+        // workspace: 4 int arrays [Rp] (keys / rows, ping-pong) + counts [G][128] + totals [128] + ranks (Rp bytes) + partial slots
+        const long long need_i = 4 * Rp + (long long)G * SORT_NB + SORT_NB + Rp / 4 + 2LL * nslots + (long long)nslots * D + 8;
+        if (need_i <= workspace_floats) {
+            int* keyA = reinterpret_cast<int*>(workspace);
+            int* keyB = keyA + Rp;
+            int* rowA = keyB + Rp;
+            int* rowB = rowA + Rp;
+            int* counts = rowB + Rp;
+            int* totals = counts + (size_t)G * SORT_NB;
+            unsigned char* rank = reinterpret_cast<unsigned char*>(totals + SORT_NB);
+            int* pkey = reinterpret_cast<int*>(rank + Rp);
+            float* pcnt = reinterpret_cast<float*>(pkey + nslots);
+            float* pvec = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(pcnt + nslots) + 15) & ~(uintptr_t)15);
+            int nbits = 1;
+            while ((1 << nbits) <= Kn) ++nbits;                      // keys 0 .. Kn (Kn = invalid) need nbits bits
+            const int passes = (nbits + SORT_BITS - 1) / SORT_BITS;
+            hipError_t e = hipMemsetAsync(cnt + k0, 0, sizeof(float) * (size_t)Kn, stream);
+            if (e == hipSuccess) e = hipMemsetAsync(sum + (size_t)k0 * D, 0, sizeof(float) * (size_t)Kn * D, stream);
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+            const int* kin = nullptr;
+            const int* rin = nullptr;
+            int* kout = keyB;
+            int* rout = rowB;
+            int* kcur = keyA;                                       // pass 0 writes the extracted keys here
+            for (int p = 0; p < passes; ++p) {
+                hipLaunchKernelGGL(vq_sort_hist_kernel, dim3((G + 3) / 4), dim3(256), 0, stream, idx, kin, R, k0, Kn, p * SORT_BITS, kcur,
+                                   counts, rank);
+                hipLaunchKernelGGL(vq_sort_scan_kernel, dim3(SORT_NB), dim3(1024), 0, stream, counts, G, totals);
+                hipLaunchKernelGGL(vq_sort_scatter_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, p == 0 ? kcur : kin, rin, R,
+                                   p * SORT_BITS, counts, totals, rank, kout, rout);
+                kin = kout; rin = rout;
+                kout = (kout == keyB) ? keyA : keyB;
+                rout = (rout == rowB) ? rowA : rowB;
+            }
+            const int nq = (D + 255) / 256;
+#define SEGR(N)                                                                                                                   \
+    case N:                                                                                                                       \
+        hipLaunchKernelGGL((vq_seg_reduce_kernel<N>), dim3((nwaves + 3) / 4), dim3(256), 0, stream, rows, ldr, kin, rin, R, D, k0, Kn, \
+                           cnt, sum, pkey, pcnt, pvec);                                                                           \
+        hipLaunchKernelGGL((vq_seg_fixup_kernel<N>), dim3((nslots + 3) / 4), dim3(256), 0, stream, pkey, pcnt, pvec, nslots, D, k0, cnt, \
+                           sum);                                                                                                  \
+        break
+            switch (nq) { SEGR(1); SEGR(2); SEGR(3); default: SEGR(4); }
+#undef SEGR
+            VQH_LAUNCH_CHECK();
+            return VQH_OK;
+        }
+    }
+    // (row chunk, code range) workgroups with an LDS table per range (see vq_segment_range_kernel): flag bit 4 selects it (A/B)
     if (workspace && !(g_vq_flags & 4) && D >= 8 && D <= 1024 && R >= 4096) {
         int KR = 1;
         while (KR * 2 * (long long)(D + 1) <= 32768 && KR * 2 <= Kn) KR *= 2;       // table <= 128 KB

@@ -138,11 +138,13 @@ def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
 
 
 @pytest.mark.parametrize("R,K,D,skew", [(262144, 8192, 256, False), (65536, 8192, 256, True), (20000, 1000, 24, False),
-                                        (16384, 4096, 512, False), (8192, 2048, 64, True)])
+                                        (16384, 4096, 512, False), (8192, 2048, 64, True), (8192, 1024, 512, True), (333, 700, 64, False),
+                                        (70000, 20000, 128, False)])
 def test_vq_segment_sums_large_tables(R, K, D, skew):
-    """EMA statistics of tables that do not fit the LDS (models/vq_vae.py:77-83: cnt = bincount, sum = one_hot^T x): the
-    (row chunk, code range) kernel against an fp64 index_add, against the one-workgroup-per-code kernel (flag bit 2), bitwise
-    reproducible, also when the codebook has collapsed onto a few codes and with -1 (masked) ids."""
+    """EMA statistics of tables that do not fit the LDS (models/vq_vae.py:77-83: cnt = bincount, sum = one_hot^T x): the sorted
+    form (stable radix sort by code + segmented sum: the default) against an fp64 index_add, against the one-workgroup-per-code
+    kernel (flag bit 2) and the (row chunk, code range) kernel (flag bit 4); bitwise reproducible, also when the codebook has
+    collapsed onto a few codes and with -1 (masked) ids."""
     from vqvae_hip import lib as L
     L.require_gpu()
     g = torch.Generator(device="cpu").manual_seed(R + K + D)
@@ -154,7 +156,7 @@ def test_vq_segment_sums_large_tables(R, K, D, skew):
     want_cnt = torch.zeros(K, device=DEV, dtype=torch.float64).index_add_(0, idx[valid], torch.ones(int(valid.sum()), device=DEV, dtype=torch.float64))
     want_sum = torch.zeros(K, D, device=DEV, dtype=torch.float64).index_add_(0, idx[valid], z[valid].double())
     outs = []
-    for flags in (0, 0, 4):
+    for flags in (0, 0, 4, 16):
         old = L.lib().vqh_vq_set_flags(flags)
         try:
             cnt = torch.full((K,), float("nan"), device=DEV)
@@ -165,7 +167,7 @@ def test_vq_segment_sums_large_tables(R, K, D, skew):
             L.lib().vqh_vq_set_flags(old)
         outs.append((cnt, ssum))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "not reproducible"
-    for cnt, ssum in (outs[0], outs[2]):
+    for cnt, ssum in (outs[0], outs[2], outs[3]):
         assert torch.equal(cnt.double(), want_cnt)
         scale = float(want_sum.abs().max())
         assert float((ssum.double() - want_sum).abs().max()) <= 2e-6 * scale * (30 if skew else 1)
