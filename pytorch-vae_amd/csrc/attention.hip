@@ -520,6 +520,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnArgs
 }
 
 #include "attention_small4.inc"
+#include "attention_x3.inc"
 
 // ---- short sequences: forward -----------------------------------------------------------------------
 // T <= 64 and S <= 64: one workgroup (2 waves) per (batch, head); Q, K, V staged once with coalesced 16-byte loads,
@@ -977,6 +978,19 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     // 4 waves (128 queries) share each staged K/V chunk when there are enough queries per (batch, head)
     const int NWq = (T >= 128) ? 4 : 2;
     dim3 grid((T + 32 * NWq - 1) / (32 * NWq), nh, B);
+    if (dh == 64 && !(g_attn_flags & 4) && aligned16(O, ldo)) {     // bf16 matrix pipes on exactly split operands (attention_x3.inc)
+        static bool attr_x3[2] = {false, false};
+        const void* fn = (NWq == 4) ? reinterpret_cast<const void*>(&attn_fwd_x3_kernel<4>) : reinterpret_cast<const void*>(&attn_fwd_x3_kernel<2>);
+        if (!attr_x3[NWq == 4]) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ax::IMG);
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+            attr_x3[NWq == 4] = true;
+        }
+        if (NWq == 4) hipLaunchKernelGGL((attn_fwd_x3_kernel<4>), grid, dim3(256), 2 * ax::IMG, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_x3_kernel<2>), grid, dim3(128), 2 * ax::IMG, stream, a);
+        VQH_LAUNCH_CHECK();
+        return VQH_OK;
+    }
 #define FWD(DH_)                                                                                              \
     if (NWq == 4) rc = launch_kv<DH_, 4>(attn_fwd_kernel<DH_, 4>, grid, a, stream);                            \
     else rc = launch_kv<DH_, 2>(attn_fwd_kernel<DH_, 2>, grid, a, stream)
@@ -1021,6 +1035,29 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     }
     const int NWq = (T >= 128) ? 4 : 2, NWk = (S >= 128) ? 4 : 2;
     dim3 gq((T + 32 * NWq - 1) / (32 * NWq), nh, B), gk((S + 32 * NWk - 1) / (32 * NWk), nh, B);
+    if (dh == 64 && !(g_attn_flags & 4) && aligned16(dQ, lddq) && aligned16(dK, lddk) && aligned16(dV, lddv)) {
+        // bf16 matrix pipes on exactly split operands (attention_x3.inc)
+        static bool attr_b[4] = {false, false, false, false};
+        const int smem_q = 2 * ax::IMG, smem_k = 2 * ax::IMG + 3 * 64 * 4;
+        const void* fq = (NWq == 4) ? reinterpret_cast<const void*>(&attn_bwd_dq_x3_kernel<4>) : reinterpret_cast<const void*>(&attn_bwd_dq_x3_kernel<2>);
+        const void* fk = (NWk == 4) ? reinterpret_cast<const void*>(&attn_bwd_dkv_x3_kernel<4>) : reinterpret_cast<const void*>(&attn_bwd_dkv_x3_kernel<2>);
+        if (!attr_b[NWq == 4]) {
+            hipError_t e = hipFuncSetAttribute(fq, hipFuncAttributeMaxDynamicSharedMemorySize, smem_q);
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+            attr_b[NWq == 4] = true;
+        }
+        if (!attr_b[2 + (NWk == 4)]) {
+            hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_k);
+            if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+            attr_b[2 + (NWk == 4)] = true;
+        }
+        if (NWq == 4) hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<4>), gq, dim3(256), smem_q, stream, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_x3_kernel<2>), gq, dim3(128), smem_q, stream, a);
+        if (NWk == 4) hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<4>), gk, dim3(256), smem_k, stream, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_x3_kernel<2>), gk, dim3(128), smem_k, stream, a);
+        VQH_LAUNCH_CHECK();
+        return VQH_OK;
+    }
 #define BWD(DH_)                                                                                          \
     if (NWq == 4) rc = launch_kv<DH_, 4>(attn_bwd_dq_kernel<DH_, 4>, gq, a, stream);                       \
     else rc = launch_kv<DH_, 2>(attn_bwd_dq_kernel<DH_, 2>, gq, a, stream);                                \

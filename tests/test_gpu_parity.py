@@ -244,7 +244,10 @@ def test_layernorm_forward_backward():
                                                           (2, 2, 33, 64, 16, False, False),
                                                           # T or S >= 128: the 4-wave general kernels, several K/V chunks
                                                           (2, 4, 160, 200, 64, False, True), (1, 2, 256, 256, 32, True, True),
-                                                          (2, 2, 130, 70, 16, False, False)])
+                                                          (2, 2, 130, 70, 16, False, False),
+                                                          # head dim 64, beyond 64 queries or keys: the bf16x3 kernels (attention_x3.inc)
+                                                          (2, 8, 350, 350, 64, True, True), (2, 8, 64, 350, 64, False, True),
+                                                          (1, 8, 350, 64, 64, False, False), (2, 2, 129, 65, 64, False, True)])
 def test_attention_forward_backward(B, nh, T, S, dh, self_attn, ragged):
     L = _hip()
     torch.manual_seed(T * S + dh)
@@ -322,6 +325,36 @@ def test_attention_short_sequence_kernels_equal_general_kernels(T, S, dh, p):
     for other in res[1:]:
         for x, y in zip(res[0], other):
             assert rel(x, y) < 2e-6
+
+
+@pytest.mark.parametrize("T,S,p", [(350, 350, 0.1), (64, 350, 0.1), (200, 96, 0.0), (130, 257, 0.25)])
+def test_attention_x3_kernels_equal_the_fp32_mfma_kernels(T, S, p):
+    """Head dim 64 beyond 64 queries / keys runs on the bf16 matrix pipes from exact 3-way operand splits (attention_x3.inc);
+    vqh_attn_set_flags bit 2 keeps the native fp32 MFMA kernels.  Same masking, the SAME dropout masks (a dropped probability is
+    dropped in both), results equal to fp32 round-off, and both as close to an fp64 evaluation."""
+    L = _hip()
+    torch.manual_seed(T + S)
+    B, nh, dh = 2, 8, 64
+    E = nh * dh
+    q, do = torch.randn(B, T, E, device=DEV), torch.randn(B, T, E, device=DEV)
+    k, v = torch.randn(B, S, E, device=DEV), torch.randn(B, S, E, device=DEV)
+    lens = torch.randint(max(1, S // 2), S + 1, (B,))
+    valid = (torch.arange(S)[None] < lens[:, None]).to(DEV)
+    rng = torch.tensor([17, 9], device=DEV, dtype=torch.int64)
+    res = []
+    for flags in (0, 4):
+        old = L.lib().vqh_attn_set_flags(flags)
+        try:
+            o, lse = torch.empty(B, T, E, device=DEV), torch.empty(B * nh * T, device=DEV)
+            L.call("vqh_attn_fwd", q, E, k, E, v, E, o, E, lse, valid, B, nh, T, S, dh, 0, rng, 5, p)
+            dq, dk, dv, dsum = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty(B * nh * T, device=DEV)
+            L.call("vqh_attn_bwd", q, E, k, E, v, E, o, E, lse, do, E, dsum, dq, E, dk, E, dv, E, valid, B, nh, T, S, dh, 0, rng, 5, p)
+            torch.cuda.synchronize()
+        finally:
+            L.lib().vqh_attn_set_flags(old)
+        res.append((o, lse, dq, dk, dv))
+    for x, y in zip(res[0], res[1]):
+        assert rel(x, y) < 2e-6
 
 
 def test_attention_dropout_gradients_match_autograd_with_extracted_mask():
