@@ -153,7 +153,12 @@ def bench_vq_only(args, dev):
         # (6 bf16 MFMA products per fp32 product) unless vqh_vq_set_flags bit 1 asks for the fp32 MFMA form
         vq_x3 = D in (64, 128, 256) and args.gemm == "x3"
         mult, peak = (X3_PRODUCTS, BF16_MFMA_PEAK_TFLOPS) if vq_x3 else (1, FP32_MFMA_PEAK_TFLOPS)
-        vq_roof = {"bound": "mfma", "kernel": ("vq_nearest_x3_kernel<%d>" % (D // 16)) if vq_x3 else ("vq_nearest_lds_kernel<%d>" % (D // 8)),
+        # form 3 = the plane-tensor kernel (D = 128 / 256, workspace permitting; its launch interval also holds the two operand
+        # split kernels, which belong to the form's cost), 2 = Z rows as register-resident planes
+        form = int(L.lib().vqh_vq_nearest_form(R, K, D, eng.ws.numel()))
+        kname = {3: "vq_nearest_p3_kernel (+ 2 x p3_split_tiled_kernel)", 2: "vq_nearest_x3_kernel<%d>" % (D // 16),
+                 1: "vq_nearest_lds_kernel<%d>" % (D // 8), 0: "vq_nearest_kernel"}[form]
+        vq_roof = {"bound": "mfma", "kernel": kname,
                    "achieved": round(mult * f / t / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                    "frac": round(mult * f / t / 1e12 / peak, 4),
                    "arithmetic": ("bf16 MFMA on exact 3-way splits, 6 products per fp32 product (executed flops = 6 x 2RKD)" if vq_x3

@@ -204,11 +204,20 @@ int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long*
  * chunk) work items spread over the whole chip, merged with the first-minimum rule */
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
                    int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);
+/* Which score kernel vqh_vq_nearest takes for a shape and workspace: 3 = plane-tensor form (D = 128 / 256, R % 256 == 0,
+ * K % 128 == 0: Z and the codebook are split once into bf16 plane tensors and scored by the LDS-DMA fed 256 x 128 tile loop of
+ * vqh_gemm_p3 with a running top-2 in registers instead of an output; taken only when the workspace holds
+ * 1.5 (R + K) D + K + 6 ns R + 16 floats MORE than the formula above, ns <= 8 the code split), 2 = rows of Z as
+ * register-resident planes against code tiles in LDS (D = 64 / 128 / 256), 1 = fp32 MFMA with code tiles in LDS, 0 = per-wave
+ * gather.  All forms return the same indices (the refinement settles every row inside the noise band exactly) */
+int vqh_vq_nearest_form(int R, int K, int D, long long workspace_floats);
+/* workspace floats with which vqh_vq_nearest takes its fastest form for the shape (the minimum above + the plane-tensor extra) */
+int vqh_vq_nearest_workspace(int R, int K, int D, long long* floats_out);
 /* diagnostic: bit 0 = always use the per-wave global-gather nearest kernel (round-1 form); bit 1 = score with the fp32 MFMA
  * instead of the bf16 pipes on exactly split operands (D = 64 / 128 / 256; same indices); segment sums of tables beyond the LDS
  * run as a stable radix sort by code + a segmented sum (skew-proof) unless bit 2 (one workgroup per code) or bit 4
- * ((row chunk, code range) workgroups with LDS tables) is set; bit 3 = one-wave-per-row refinement instead of the chip-wide one
- * (A/B runs: same results); returns the previous flags */
+ * ((row chunk, code range) workgroups with LDS tables) is set; bit 3 = one-wave-per-row refinement instead of the chip-wide one;
+ * bit 5 = never take the plane-tensor score form (A/B runs: same results); returns the previous flags */
 int vqh_vq_set_flags(int flags);
 /* live timing of the nearest-neighbour main kernel with HIP events on its launch stream (bench.py --vq-only):
  * begin(), eager calls, end(out) with out = double[3] = {launches, kernel seconds, sum of 2*R*K*D} */

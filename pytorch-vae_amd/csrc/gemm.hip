@@ -1267,6 +1267,8 @@ int launch_p3(const P3Args& g, int splits, hipStream_t stream) {
     // persistent: at most one resident workgroup per CU (144 KB of LDS each), each walking its share of the tiles x splits
     const int n_items = (g.M / p3::TBM) * (g.N / p3::TBN) * splits;
     dim3 grid(std::min(n_items, p3_num_cus()));
+    // the kernel's stage parity is static: a workgroup that walks several items needs an even number of K-steps per item
+    if (((g.kchunk / p3::TBK) & 1) && n_items > (int)grid.x) grid.x = n_items;
     ProfRec rec{};
     if (g_prof_on) {
         rec.slot = prof_slot(A_KC, B_KC, MODE, 5);
@@ -1288,6 +1290,66 @@ inline bool p3_tensor_ok(const void* P, long long pitch, int cols) {
     return P && (reinterpret_cast<uintptr_t>(P) & 15) == 0 && (pitch % 16) == 0 && pitch >= (long long)cols * 6;
 }
 }  // namespace
+
+// Internal (vq.hip): scores of R rows of Z against K codes on pre-split operands, top-2 partials per (slot, row).
+// Z / E: fp32 [R][D] and [K][D], split here into stage images Zp (6 R D bytes) and Ep (6 K D bytes); nb_init[K]; partial arrays
+// [2 * nsplit][R].  R % 256 == 0, K % (128 * nsplit) == 0, D % 64 == 0 (an even number of K-steps per tile), at most 32 code
+// tiles per workgroup (their start values sit in the 16 KB of LDS behind the two stages).
+extern "C" __attribute__((visibility("hidden"))) int vqh_internal_nearest_p3(const float* Z, int ldz, const float* E, int lde, void* Zp, void* Ep,
+                                                                            const float* nb_init, float* pbest, float* psecond, int* pidx,
+                                                                            int R, int K, int D, int nsplit, hipStream_t stream) {
+    VQH_CHECK_ARG(R > 0 && K > 0 && nsplit > 0 && (R % p3::TBM) == 0 && (K % (p3::TBN * nsplit)) == 0 && (D % 64) == 0 &&
+                      K / p3::TBN / nsplit <= 32,
+                  "nearest_p3: shape not eligible");
+    VQH_CHECK_ARG(Z && E && Zp && Ep && ((reinterpret_cast<uintptr_t>(Zp) | reinterpret_cast<uintptr_t>(Ep)) & 15) == 0 && nb_init && pbest &&
+                      psecond && pidx, "nearest_p3: bad operand");
+    {
+        const long long tz = (long long)R * (D / 8), te = (long long)K * (D / 8);
+        hipLaunchKernelGGL(p3_split_tiled_kernel, dim3((unsigned)std::min<long long>((tz + 255) / 256, 1 << 16)), dim3(256), 0, stream, Z,
+                           (long long)ldz, static_cast<char*>(Zp), R, D, p3::TBM);
+        hipLaunchKernelGGL(p3_split_tiled_kernel, dim3((unsigned)std::min<long long>((te + 255) / 256, 1 << 16)), dim3(256), 0, stream, E,
+                           (long long)lde, static_cast<char*>(Ep), K, D, p3::TBN);
+    }
+    const long long pz = (long long)D * 6, pe = (long long)D * 6;
+    const int lds_bytes = p3::LDS_BYTES + (K / p3::TBN / nsplit) * p3::TBN * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_nearest_p3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    P3Args g{};
+    g.A = static_cast<const char*>(Zp); g.B = static_cast<const char*>(Ep);
+    g.pa = pz; g.pb = pe;
+    g.M = R; g.N = K; g.K = D; g.kchunk = D;
+    g.mode = EPI_NEAREST;
+    g.nb_init = nb_init; g.nb_best = pbest; g.nb_second = psecond; g.nb_idx = pidx;
+    const int per = K / p3::TBN / nsplit;
+#ifdef P3_STAMPS
+    static unsigned long long* stamp_buf = nullptr;
+    const int nwg = (R / p3::TBM) * nsplit;
+    if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)65536 * 64);
+    g.aux_out = reinterpret_cast<float*>(stamp_buf);
+#endif
+    hipLaunchKernelGGL(vq_nearest_p3_kernel, dim3((R / p3::TBM) * nsplit), dim3(512), lds_bytes, stream, g, per, nsplit);
+    VQH_LAUNCH_CHECK();
+#ifdef P3_STAMPS
+    {
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> hb((size_t)nwg * 8);
+        (void)hipMemcpy(hb.data(), stamp_buf, hb.size() * 8, hipMemcpyDeviceToHost);
+        double tot = 0, real = 0, loop = 0, epi = 0, vm = 0, bar = 0, iss = 0, Q = 0;
+        for (int w = 0; w < nwg; ++w) {
+            tot += hb[w * 8 + 0]; real += hb[w * 8 + 1]; loop += hb[w * 8 + 2]; epi += (double)(hb[w * 8 + 3] >> 20); Q += (double)(hb[w * 8 + 3] & 0xfffff);
+            vm += hb[w * 8 + 4]; bar += hb[w * 8 + 5]; iss += hb[w * 8 + 6];
+        }
+        fprintf(stderr, "[p3n stamps] R=%d K=%d D=%d ns=%d wgs=%d | per wg: total %.0f cyc (%.1f us real @100MHz ticks %.0f) loop %.0f epi %.0f | per K-step: loop %.0f epi %.0f | loader: vm-wait %.0f barrier %.0f issue %.0f per step\n",
+                R, K, D, nsplit, nwg, tot / nwg, real / nwg / 100.0, real / nwg, loop / nwg, epi / nwg, loop / Q, epi / Q, vm / Q, bar / Q, iss / Q);
+    }
+#endif
+    return VQH_OK;
+}
 
 // 1 when vqh_gemm_p3 accepts the shape (the caller keeps fp32 operands and vqh_gemm for everything else)
 extern "C" int vqh_gemm_p3_eligible(int M, int N, int K) {

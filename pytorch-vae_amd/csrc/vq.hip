@@ -489,6 +489,13 @@ __global__ __launch_bounds__(256, (NT16 >= 16) ? 1 : 2) void vq_nearest_x3_kerne
     }
 }
 
+// start values of the plane-tensor score kernel (gemm_p3.inc, EPI_NEAREST): -|e|^2 / 2, or -inf for a code that is an exact copy
+// of a lower one (it can neither win -- the lower index has the same score -- nor count as a rival)
+__global__ void vq_p3_init_kernel(const float* __restrict__ enorm, const int* __restrict__ canon, int K, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = (canon[k] == k) ? -0.5f * enorm[k] : -INFINITY;
+}
+
 // merge the per-range partials (ascending code ranges), write the index and flag rows whose top-2 gap is inside the
 // fp32 noise band; bestval keeps the winning score for the refinement's pre-filter.
 __global__ void vq_combine_kernel(const float* __restrict__ pbest, const float* __restrict__ psecond,
@@ -1217,14 +1224,16 @@ extern "C" int vqh_vq_profile_end(double* out) {
 // workspace (floats): hash table (3 T, T = power of two >= 2K) + K hashes (2K) + canon (K) + K code norms + R row norms +
 // R best scores + nsplit*R*(best, second, index) + R/4 flag bytes + the split codebook + the refinement's list of flagged rows
 // (R + 4) and partials (3 * min(R, 16384) * ceil(K / 256))
-extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset,
-                              int R, int K, int D, float rel_tol, float* workspace, long long workspace_floats,
-                              hipStream_t stream) {
-    VQH_CHECK_ARG(R >= 0 && K > 0 && D > 0 && (D % 8) == 0, "vqh_vq_nearest: D must be a positive multiple of 8");
-    if (R == 0) return VQH_OK;
-    VQH_CHECK_ARG(Z && E && idx_out && workspace, "vqh_vq_nearest: null pointer");
-    VQH_CHECK_ARG(((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(E)) & 15) == 0 && (ldz & 3) == 0 && (lde & 3) == 0,
-                  "vqh_vq_nearest: operands must be 16-byte aligned");
+extern "C" int vqh_p3_split(const float* X, int ldx, void* P, long long pitch_bytes, int rows, int cols, hipStream_t stream);
+extern "C" int vqh_internal_nearest_p3(const float* Z, int ldz, const float* E, int lde, void* Zp, void* Ep, const float* nb_init, float* pbest,
+                                       float* psecond, int* pidx, int R, int K, int D, int nsplit, hipStream_t stream);
+
+struct VqNearestPlan {
+    bool lds_form, x3_form;
+    long long ex_floats, refine_floats, need;
+    int rows_per_block, row_blocks, nsplit, kchunk, T, CH, cap;
+};
+static VqNearestPlan vq_nearest_plan(int R, int K, int D) {
     // LDS-staged kernel: 128 rows per workgroup; D/8 in {1,2,4,8,16,32}
     const int nt8 = D / 8;
     const bool lds_form = !(g_vq_flags & 1) && D <= 256 && (nt8 & (nt8 - 1)) == 0;
@@ -1250,7 +1259,60 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     const int cap = R < 16384 ? R : 16384;
     const long long refine_floats = 4 + (long long)R + 3LL * cap * CH + 2;
     const long long need = 3LL * T + 4LL * K + 2LL * R + 3LL * nsplit * R + (R + 3) / 4 + 8 + ex_floats + 4 + refine_floats;
+    return VqNearestPlan{lds_form, x3_form, ex_floats, refine_floats, need, rows_per_block, row_blocks, nsplit, kchunk, T, CH, cap};
+}
+// Extra workspace floats of the plane-tensor form and its code split, 0 when the shape is not taken by it: whole 256-row and
+// 128-code tiles, D = 128 / 256, at least 96 workgroups after splitting the code range (each keeps >= 16 K-steps).
+static long long vq_p3_extra_floats(int R, int K, int D, int* ns_out) {
+    if ((g_vq_flags & (1 | 2 | 32)) || !(D == 128 || D == 256) || R <= 0 || (R % 256) != 0 || (K % 128) != 0) return 0;
+    // the code range is split 8 ways where possible, not only for few rows: the workgroups of one row tile share its Z planes
+    // through one XCD's L2 (vq_nearest_p3_kernel)
+    const int mt = R / 256, tn = K / 128, nk = D / 32;
+    int ns = 1;
+    while (ns < 8 && (tn % (2 * ns)) == 0 && (tn / (2 * ns)) * nk >= 16) ns *= 2;
+    if (mt * ns < 96 || tn / ns > 32) return 0;
+    if (ns_out) *ns_out = ns;
+    return 3LL * R * D / 2 + 3LL * K * D / 2 + K + 6LL * ns * R + 16;
+}
+// 3 = plane-tensor form, 2 = register-resident split form, 1 = fp32 MFMA with the codebook through LDS, 0 = per-wave gather
+extern "C" int vqh_vq_nearest_form(int R, int K, int D, long long workspace_floats) {
+    if (R <= 0 || K <= 0 || D <= 0 || (D % 8) != 0) return 0;
+    const VqNearestPlan pl = vq_nearest_plan(R, K, D);
+    if (pl.x3_form) {
+        const long long extra = vq_p3_extra_floats(R, K, D, nullptr);
+        return (extra > 0 && extra + pl.need <= workspace_floats) ? 3 : 2;
+    }
+    return pl.lds_form ? 1 : 0;
+}
+
+// workspace floats with which vqh_vq_nearest takes its fastest form for the shape (>= the documented minimum)
+extern "C" int vqh_vq_nearest_workspace(int R, int K, int D, long long* floats_out) {
+    VQH_CHECK_ARG(floats_out && R >= 0 && K > 0 && D > 0 && (D % 8) == 0, "vqh_vq_nearest_workspace: bad argument");
+    const VqNearestPlan pl = vq_nearest_plan(R > 0 ? R : 1, K, D);
+    *floats_out = pl.need + (pl.x3_form ? vq_p3_extra_floats(R, K, D, nullptr) : 0);
+    return VQH_OK;
+}
+
+extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset,
+                              int R, int K, int D, float rel_tol, float* workspace, long long workspace_floats,
+                              hipStream_t stream) {
+    VQH_CHECK_ARG(R >= 0 && K > 0 && D > 0 && (D % 8) == 0, "vqh_vq_nearest: D must be a positive multiple of 8");
+    if (R == 0) return VQH_OK;
+    VQH_CHECK_ARG(Z && E && idx_out && workspace, "vqh_vq_nearest: null pointer");
+    VQH_CHECK_ARG(((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(E)) & 15) == 0 && (ldz & 3) == 0 && (lde & 3) == 0,
+                  "vqh_vq_nearest: operands must be 16-byte aligned");
+    const VqNearestPlan pl = vq_nearest_plan(R, K, D);
+    const bool lds_form = pl.lds_form, x3_form = pl.x3_form;
+    const int nt8 = D / 8;
+    const long long ex_floats = pl.ex_floats, need = pl.need;
+    const int row_blocks = pl.row_blocks, nsplit = pl.nsplit, kchunk = pl.kchunk, T = pl.T, CH = pl.CH, cap = pl.cap;
     VQH_CHECK_ARG(need <= workspace_floats, "vqh_vq_nearest: workspace too small");
+    // Plane-tensor form (D = 128 / 256, whole 256-row and 128-code tiles): Z and the codebook are split once into bf16 plane
+    // tensors and scored by the LDS-DMA fed 256 x 128 tile loop of gemm_p3.inc with a running top-2 instead of an output
+    // (vq_nearest_p3_kernel).  It needs 1.5 (R + K) D + K + 6 ns R more workspace floats and is taken when the caller gave them.
+    int ns3 = 1;
+    const long long p3_floats = x3_form ? vq_p3_extra_floats(R, K, D, &ns3) : 0;
+    const bool p3_form = p3_floats > 0 && need + p3_floats <= workspace_floats;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);       // 2T floats, 8-byte aligned
     int* minidx = reinterpret_cast<int*>(workspace + 2 * (size_t)T);
     unsigned long long* hash = reinterpret_cast<unsigned long long*>(workspace + 3 * (size_t)T);   // 2K floats
@@ -1284,7 +1346,20 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
             return VQH_ERR_LAUNCH;
         }
     }
-    if (x3_form) {
+    int n_partials = nsplit;
+    if (p3_form) {
+        float* base = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace + need) + 15) & ~(uintptr_t)15);
+        char* Zp = reinterpret_cast<char*>(base);
+        char* Ep = Zp + (size_t)R * D * 6;
+        float* nb_init = reinterpret_cast<float*>(Ep + (size_t)K * D * 6);
+        n_partials = 2 * ns3;
+        pbest = nb_init + K;
+        psecond = pbest + (size_t)n_partials * R;
+        pidx = reinterpret_cast<int*>(psecond + (size_t)n_partials * R);
+        hipLaunchKernelGGL(vq_p3_init_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, enorm, canon, K, nb_init);
+        const int rc = vqh_internal_nearest_p3(Z, ldz, E, lde, Zp, Ep, nb_init, pbest, psecond, pidx, R, K, D, ns3, stream);
+        if (rc != VQH_OK) return rc;
+    } else if (x3_form) {
         const int nt16 = D / 16;
         const int ct = (nt16 >= 16) ? 32 : 64;
         const size_t smem = (size_t)2 * ct * (6 * D + 16) + (size_t)4 * ct * sizeof(float);
@@ -1330,7 +1405,7 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
         }
         g_vq_prof.push_back(rec);
     }
-    hipLaunchKernelGGL(vq_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, pbest, psecond, pidx, canon, nsplit, znorm,
+    hipLaunchKernelGGL(vq_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, pbest, psecond, pidx, canon, n_partials, znorm,
                        idx_out, idx_offset, amb, bestval, R, rel_tol);
     if (g_vq_flags & 8) {                  // A/B: the one-wave-per-row refinement
         hipLaunchKernelGGL(vq_refine_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, ldz, E, lde, idx_out, idx_offset, amb,

@@ -757,6 +757,12 @@ class StepEngine:
         multi = dp_active()
         rows = z_e
         res = [self.T("vq.res0", R, D), self.T("vq.res1", R, D)]
+        # the plane-tensor score form wants room for the split Z / codebook images; the workspace can only move while no
+        # captured graph holds its address (eager steps come first)
+        want = L.vq_nearest_workspace(R, Kp, D)
+        if (want > self.ws.numel() and not torch.cuda.is_current_stream_capturing()
+                and not any(a.graphs for a in self.arenas.values())):
+            self.ws = torch.empty(want, device=self.dev, dtype=torch.float32)
         for lv in range(Q):
             lo = lv * Kp
             tab = emb[lo:lo + Kp]

@@ -61,7 +61,7 @@ _PROTOS = {
     "vqh_adamw_step": "pppplppp",
 }
 _CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "l": C.c_longlong, "u": C.c_uint}
-EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_p3_eligible", "vqh_gemm_set_flags", "vqh_attn_set_flags", "vqh_gemm_profile_begin", "vqh_gemm_profile_end",
+EXPORTS = ["vqh_last_error", "vqh_abi_version", "vqh_gemm_p3_eligible", "vqh_vq_nearest_form", "vqh_vq_nearest_workspace", "vqh_gemm_set_flags", "vqh_attn_set_flags", "vqh_gemm_profile_begin", "vqh_gemm_profile_end",
            "vqh_vq_set_flags", "vqh_vq_profile_begin", "vqh_vq_profile_end"] + list(_PROTOS)
 
 
@@ -77,6 +77,10 @@ def lib():
         L.vqh_abi_version.restype = C.c_int
         L.vqh_gemm_p3_eligible.argtypes = [C.c_int, C.c_int, C.c_int]
         L.vqh_gemm_p3_eligible.restype = C.c_int
+        L.vqh_vq_nearest_form.argtypes = [C.c_int, C.c_int, C.c_int, C.c_longlong]
+        L.vqh_vq_nearest_form.restype = C.c_int
+        L.vqh_vq_nearest_workspace.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+        L.vqh_vq_nearest_workspace.restype = C.c_int
         L.vqh_gemm_profile_end.argtypes = [C.c_void_p]
         L.vqh_vq_profile_end.argtypes = [C.c_void_p]
         for name, sig in _PROTOS.items():
@@ -99,6 +103,15 @@ def lib():
                 print(f"[vqvae_hip] {env}={val} applied ({setter}): kernel A/B override for this process", file=sys.stderr)
         _lib = L
     return _lib
+
+
+def vq_nearest_workspace(R, K, D):
+    """Workspace floats with which vqh_vq_nearest takes its fastest form for the shape."""
+    out = C.c_longlong(0)
+    rc = lib().vqh_vq_nearest_workspace(int(R), int(K), int(D), C.byref(out))
+    if rc != 0:
+        raise VqhError(f"vqh_vq_nearest_workspace failed (rc={rc}): {lib().vqh_last_error().decode()}")
+    return int(out.value)
 
 
 def require_gpu():

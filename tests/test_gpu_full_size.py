@@ -110,7 +110,7 @@ def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
     emb = torch.randn(K, D, device=DEV) / D ** 0.5
     emb[K // 3] = emb[7]                                 # exact duplicate codes: the lower index must win
     z[5] = emb[7]
-    ws = torch.empty(48 * 1024 * 1024, device=DEV)
+    ws = torch.empty(160 * 1024 * 1024, device=DEV)     # room for the plane-tensor form where the shape allows it
     got = []
     for flags in (0, 1, 8):                              # default | per-wave gather kernel | one-wave-per-row refinement
         old = L.lib().vqh_vq_set_flags(flags)
@@ -135,6 +135,53 @@ def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
         ok = (dd[:, 0] < dd[:, 1]) | ((dd[:, 0] == dd[:, 1]) & (cand[:, 0] <= cand[:, 1]))
         assert bool(ok.all()), f"{int((~ok).sum())} rows are not the exact nearest code"
     assert int(got[0][5]) == 7
+
+
+@pytest.mark.parametrize("R,K,D", [(262144, 8192, 256), (65536, 1024, 128), (16384, 8192, 256), (24576, 2048, 128), (49152, 512, 256)])
+def test_vq_nearest_plane_tensor_form_equals_the_register_form_and_the_fp64_argmin(R, K, D):
+    """The plane-tensor score kernel (vq_nearest_p3_kernel: Z and the codebook pre-split, 256 x 128 tiles fed by LDS-DMA, top-2 in
+    registers) is taken when the workspace allows it (vqh_vq_nearest_form == 3) and returns the indices of the register-resident
+    form (vq flags bit 5) and of an fp64 brute force: duplicated codes, rows sitting on a code, rows exactly between two codes,
+    a code split for few rows (R = 16384 -> 4 code ranges) included (models/vq_vae.py:183-188, :238-244)."""
+    from vqvae_hip import lib as L
+    L.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(R + K + D)
+    emb = torch.randn(K, D, generator=g) / D ** 0.5
+    emb[K // 2] = emb[3]                                      # exact duplicates: the lower index must win
+    emb[K - 1] = emb[130 % K]
+    z = torch.randn(R, D, generator=g) / D ** 0.5
+    z[:64] = emb[torch.randint(0, K, (64,), generator=g)]     # rows sitting on a code
+    z[64:96] = 0.5 * (emb[10] + emb[11])                      # rows exactly between two codes
+    z[96] = emb[K // 2]
+    emb, z = emb.to(DEV), z.to(DEV)
+    ws = torch.empty(160 << 20, device=DEV)
+    assert L.lib().vqh_vq_nearest_form(R, K, D, ws.numel()) == 3
+    assert L.lib().vqh_vq_nearest_form(R, K, D, 40 << 20) in (2, 3)
+    got = []
+    for flags in (0, 32):
+        old = L.lib().vqh_vq_set_flags(flags)
+        try:
+            assert L.lib().vqh_vq_nearest_form(R, K, D, ws.numel()) == (3 if flags == 0 else 2)
+            idx = torch.full((R,), -1, device=DEV, dtype=torch.int64)
+            L.call("vqh_vq_nearest", z, D, emb, D, idx, 0, R, K, D, 3e-5, ws, ws.numel())
+            torch.cuda.synchronize()
+        finally:
+            L.lib().vqh_vq_set_flags(old)
+        got.append(idx)
+    assert torch.equal(got[0], got[1]), int((got[0] != got[1]).sum())
+    assert int(got[0][96]) == 3
+    e64 = emb.double()
+    want = torch.empty(R, dtype=torch.int64, device=DEV)
+    for lo in range(0, R, 8192):                              # direct form in fp64 for the candidates of every row
+        zc = z[lo:lo + 8192].double()
+        d = (zc * zc).sum(1, keepdim=True) - 2.0 * zc @ e64.t() + (e64 * e64).sum(1)[None]
+        want[lo:lo + 8192] = d.argmin(1)
+    bad = torch.nonzero(got[0] != want).flatten()
+    if bad.numel():
+        zc, cand = z[bad].double(), torch.stack([got[0][bad], want[bad]], 1)
+        dd = ((zc[:, None, :] - e64[cand]) ** 2).sum(-1)
+        ok = (dd[:, 0] < dd[:, 1]) | ((dd[:, 0] == dd[:, 1]) & (cand[:, 0] <= cand[:, 1]))
+        assert bool(ok.all()), f"{int((~ok).sum())} rows are not the exact nearest code"
 
 
 @pytest.mark.parametrize("R,K,D,skew", [(262144, 8192, 256, False), (65536, 8192, 256, True), (20000, 1000, 24, False),
