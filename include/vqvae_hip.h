@@ -188,8 +188,9 @@ int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* 
                  float* dV, int lddv, const unsigned char* kvalid, int B, int nh, int T, int S, int dh, int qkv_shared,
                  const unsigned long long* rng_state, unsigned drop_site, float drop_p, vqh_stream_t stream);
 /* diagnostic: bit 0 = do not use the fused short-sequence (T,S <= 64) kernels; bit 1 = short-sequence backward in its
- * round-1 two-wave-group form instead of the quartered one; bit 2 = the general kernels of head dim 64 on the native fp32 MFMA
- * instead of the bf16 pipes fed by exact 3-way operand splits (A/B runs: same results to fp32 round-off); returns the previous flags */
+ * round-1 two-wave-group form instead of the quartered one; bit 2 = the kernels of head dim 64 (general ones and the short-sequence
+ * backward) on the native fp32 MFMA instead of the bf16 pipes fed by exact 3-way operand splits (A/B runs: same results to fp32
+ * round-off); returns the previous flags */
 int vqh_attn_set_flags(int flags);
 
 /* ids of positions outside `valid` (bytes, 1 = valid) become -1, which the statistics entry points below ignore:
@@ -204,7 +205,7 @@ int vqh_vq_mask_ids(const long long* idx, const unsigned char* valid, long long*
  * chunk) work items spread over the whole chip, merged with the first-minimum rule */
 int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, long long* idx_out, int idx_offset, int R, int K,
                    int D, float rel_tol, float* workspace, long long workspace_floats, vqh_stream_t stream);
-/* Which score kernel vqh_vq_nearest takes for a shape and workspace: 3 = plane-tensor form (D = 128 / 256, R % 256 == 0,
+/* Which score kernel vqh_vq_nearest takes for a shape and workspace: 3 = plane-tensor form (D = 128 / 256 / 512, R % 256 == 0,
  * K % 128 == 0: Z and the codebook are split once into bf16 plane tensors and scored by the LDS-DMA fed 256 x 128 tile loop of
  * vqh_gemm_p3 with a running top-2 in registers instead of an output; taken only when the workspace holds
  * 1.5 (R + K) D + K + 6 ns R + 16 floats MORE than the formula above, ns <= 8 the code split), 2 = rows of Z as

@@ -1026,6 +1026,19 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
     a.dO = dO; a.lddo = lddo; a.Dsum = Dsum; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
     if (T <= 64 && S <= 64 && aligned16(dQ, lddq) && aligned16(dK, lddk) && aligned16(dV, lddv) && !(g_attn_flags & 1)) {
         int rc = VQH_OK;
+        if (dh == 64 && !(g_attn_flags & (2 | 4))) {           // bf16 matrix pipes on exactly split operands (attention_x3.inc)
+            static bool attr_set = false;
+            const int smem = 3 * ax::IMG + 3 * 64 * 4;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_x3_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(attn_bwd_small_x3_kernel, dim3(1, nh, B), dim3(256), smem, stream, a);
+            VQH_LAUNCH_CHECK();
+            return VQH_OK;
+        }
         switch (dh) {
             case 16: rc = launch_bwd_small<16>(a, stream); break;
             case 32: rc = launch_bwd_small<32>(a, stream); break;

@@ -1262,9 +1262,9 @@ static VqNearestPlan vq_nearest_plan(int R, int K, int D) {
     return VqNearestPlan{lds_form, x3_form, ex_floats, refine_floats, need, rows_per_block, row_blocks, nsplit, kchunk, T, CH, cap};
 }
 // Extra workspace floats of the plane-tensor form and its code split, 0 when the shape is not taken by it: whole 256-row and
-// 128-code tiles, D = 128 / 256, at least 96 workgroups after splitting the code range (each keeps >= 16 K-steps).
+// 128-code tiles, D = 128 / 256 / 512, at least 96 workgroups after splitting the code range (each keeps >= 16 K-steps).
 static long long vq_p3_extra_floats(int R, int K, int D, int* ns_out) {
-    if ((g_vq_flags & (1 | 2 | 32)) || !(D == 128 || D == 256) || R <= 0 || (R % 256) != 0 || (K % 128) != 0) return 0;
+    if ((g_vq_flags & (1 | 2 | 32)) || !(D == 128 || D == 256 || D == 512) || R <= 0 || (R % 256) != 0 || (K % 128) != 0) return 0;
     // the code range is split 8 ways where possible, not only for few rows: the workgroups of one row tile share its Z planes
     // through one XCD's L2 (vq_nearest_p3_kernel)
     const int mt = R / 256, tn = K / 128, nk = D / 32;
@@ -1278,18 +1278,16 @@ static long long vq_p3_extra_floats(int R, int K, int D, int* ns_out) {
 extern "C" int vqh_vq_nearest_form(int R, int K, int D, long long workspace_floats) {
     if (R <= 0 || K <= 0 || D <= 0 || (D % 8) != 0) return 0;
     const VqNearestPlan pl = vq_nearest_plan(R, K, D);
-    if (pl.x3_form) {
-        const long long extra = vq_p3_extra_floats(R, K, D, nullptr);
-        return (extra > 0 && extra + pl.need <= workspace_floats) ? 3 : 2;
-    }
-    return pl.lds_form ? 1 : 0;
+    const long long extra = vq_p3_extra_floats(R, K, D, nullptr);
+    if (extra > 0 && extra + pl.need <= workspace_floats) return 3;
+    return pl.x3_form ? 2 : pl.lds_form ? 1 : 0;
 }
 
 // workspace floats with which vqh_vq_nearest takes its fastest form for the shape (>= the documented minimum)
 extern "C" int vqh_vq_nearest_workspace(int R, int K, int D, long long* floats_out) {
     VQH_CHECK_ARG(floats_out && R >= 0 && K > 0 && D > 0 && (D % 8) == 0, "vqh_vq_nearest_workspace: bad argument");
     const VqNearestPlan pl = vq_nearest_plan(R > 0 ? R : 1, K, D);
-    *floats_out = pl.need + (pl.x3_form ? vq_p3_extra_floats(R, K, D, nullptr) : 0);
+    *floats_out = pl.need + vq_p3_extra_floats(R, K, D, nullptr);
     return VQH_OK;
 }
 
@@ -1311,7 +1309,7 @@ extern "C" int vqh_vq_nearest(const float* Z, int ldz, const float* E, int lde, 
     // tensors and scored by the LDS-DMA fed 256 x 128 tile loop of gemm_p3.inc with a running top-2 instead of an output
     // (vq_nearest_p3_kernel).  It needs 1.5 (R + K) D + K + 6 ns R more workspace floats and is taken when the caller gave them.
     int ns3 = 1;
-    const long long p3_floats = x3_form ? vq_p3_extra_floats(R, K, D, &ns3) : 0;
+    const long long p3_floats = vq_p3_extra_floats(R, K, D, &ns3);
     const bool p3_form = p3_floats > 0 && need + p3_floats <= workspace_floats;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);       // 2T floats, 8-byte aligned
     int* minidx = reinterpret_cast<int*>(workspace + 2 * (size_t)T);

@@ -174,6 +174,19 @@ class StepEngine:
         self.group_wgrad = os.environ.get("VQH_GROUP_WGRAD", "1") != "0"
         self._wq = []
         self._dy_slot = 0
+        # EXPERIMENT, off by default (VQH_OVERLAP_WGRAD=1): the grouped weight-gradient launch of a layer on a SECOND stream
+        # while the main stream goes on with the next layer's backward (nothing reads a weight gradient before the clip), so
+        # that the prologue / epilogue / drain gaps of one kernel are filled with workgroups of the other.  Measured on C2:
+        # 27.04 ms per step against 26.64 ms in order -- both kernels want a whole CU's LDS, so they only alternate, and two
+        # operand working sets share each XCD's L2.  Results are identical (same kernels, same order per gradient).
+        # Single process only: with several ranks a phase's gradients must be final at its bucket's all-reduce, and a graph
+        # segment has to rejoin its forked streams.
+        self.overlap_wgrad = self.group_wgrad and os.environ.get("VQH_OVERLAP_WGRAD", "0") == "1"
+        self._side = None                     # the second stream
+        self._ws_side = None                  # its own split-K workspace
+        self._side_busy = False
+        self._par = 0                         # parity of the operand buffers handed out by TW()
+        self._buf_ev = {}                     # storage pointer of an operand buffer -> event of the side launch that reads it
 
     @property
     def m(self):
@@ -314,7 +327,7 @@ class StepEngine:
         dxd, site, p = None, 0, 0.0
         if emit is not None and emit[1] > 0.0 and self.fold_dropout_bwd:
             site, p = emit[0], emit[1]
-            dxd = self.T(emit[2], rows * self.H)
+            dxd = self.TW(emit[2], rows * self.H)
         call("vqh_layernorm_bwd", dy, lddy, x, ldx, self.P[name + ".weight"], self.buf[tag + ".mean"],
              self.buf[tag + ".rstd"], dx, lddx, int(accumulate), self.G[name + ".weight"], self.G[name + ".bias"], 0.0,
              rows, self.H, dxd, self.rng if dxd is not None else None, site, p, self.ws, self.ws.numel())
@@ -342,9 +355,41 @@ class StepEngine:
     def flush_wgrads(self):
         """Run the queued weight-gradient products of the layer just finished as one grouped launch."""
         if self._wq:
-            L.wgrad_group(self._wq, self.ws)
+            from .parallel import dp_active
+            if self.overlap_wgrad and not dp_active():
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.dev)
+                    self._ws_side = torch.empty(WS_FLOATS, device=self.dev, dtype=torch.float32)
+                self._side.wait_stream(main)              # operands and the gradients' earlier contents are ordered before it
+                with torch.cuda.stream(self._side):
+                    L.wgrad_group(self._wq, self._ws_side)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                for it in self._wq:                       # whoever rewrites an operand buffer waits for this launch (TW)
+                    self._buf_ev[it[0].untyped_storage().data_ptr()] = ev
+                self._side_busy = True
+            else:
+                L.wgrad_group(self._wq, self.ws)
             self._wq = []
         self._dy_slot = 0
+        self._par ^= 1
+
+    def join_wgrads(self):
+        """The main stream waits for every weight-gradient launch of the second stream (before anything reads a gradient)."""
+        if self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_busy = False
+        self._buf_ev.clear()
+
+    def TW(self, name, *shape):
+        """A scratch buffer that a DEFERRED weight-gradient product will read (its dY operand): two copies alternate from layer
+        to layer, and a copy is handed out again only after the launch that read it (recorded in flush_wgrads)."""
+        t = self.T(f"{name}@{self._par}" if self.overlap_wgrad else name, *shape)
+        ev = self._buf_ev.pop(t.untyped_storage().data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return t
 
     def dy_tag(self):
         """Name of a fresh buffer for a block's output gradient (valid until the next flush_wgrads)."""
@@ -359,10 +404,10 @@ class StepEngine:
                 return dy
             # the residual-stream gradient is updated in place later in the block, but a deferred weight-gradient product
             # still reads this value: give it its own copy
-            out = self.T(tag, n)
+            out = self.TW(tag, n)
             call("vqh_copy2d", dy, n, out, n, 1, n)
             return out
-        out = self.T(tag, n)
+        out = self.TW(tag, n)
         call("vqh_dropout_bwd", dy, out, n, self.rng, site, p)
         return out
 
@@ -405,23 +450,23 @@ class StepEngine:
         site = self.site(pre + ".attn_drop")
         if self_attn:
             qkv = self.buf[pre + ".qkv"]
-            dqkv = self.T("tmp.dqkv", rows_q, 3 * H)
+            dqkv = self.TW("tmp.dqkv", rows_q, 3 * H)
             call("vqh_attn_bwd", qkv, 3 * H, qkv[:, H:], 3 * H, qkv[:, 2 * H:], 3 * H, ao, H, lse, d_ao, H, dsum,
                  dqkv, 3 * H, dqkv[:, H:], 3 * H, dqkv[:, 2 * H:], 3 * H, kvalid, B, nh, T, S, H // nh, flag, self.rng, site, p_attn)
             if shared:
-                dsh = self.T("tmp.dqkv_sh", T, 3 * H)
+                dsh = self.TW("tmp.dqkv_sh", T, 3 * H)
                 call("vqh_colsum", dqkv, T * 3 * H, B, T * 3 * H, dsh, 0.0, self.ws, self.ws.numel())
                 dqkv, rows_q = dsh, T
             self.lin_wgrad(dqkv, 3 * H, q_in, H, rows_q, gW, gb)
             self.lin_dgrad(dqkv, 3 * H, rows_q, W, d_q_in, H)
         else:
             qp, kvp = self.buf[pre + ".q"], self.buf[pre + ".kv"]
-            dq = self.T("tmp.dq", rows_q, H)
-            dkv = self.T("tmp.dkv", rows_kv, 2 * H)
+            dq = self.TW("tmp.dq", rows_q, H)
+            dkv = self.TW("tmp.dkv", rows_kv, 2 * H)
             call("vqh_attn_bwd", qp, H, kvp, 2 * H, kvp[:, H:], 2 * H, ao, H, lse, d_ao, H, dsum,
                  dq, H, dkv, 2 * H, dkv[:, H:], 2 * H, kvalid, B, nh, T, S, H // nh, flag, self.rng, site, p_attn)
             if shared:
-                dsh = self.T("tmp.dq_sh", T, H)
+                dsh = self.TW("tmp.dq_sh", T, H)
                 call("vqh_colsum", dq, T * H, B, T * H, dsh, 0.0, self.ws, self.ws.numel())
                 dq, rows_q = dsh, T
             self.lin_wgrad(dq, H, q_in, H, rows_q, gW[:H], gb[:H])
@@ -500,7 +545,7 @@ class StepEngine:
         if act == "relu":
             # d pre-activation: written over the saved post-activation (read-then-write per element), unless the weight
             # gradient of linear2 -- which needs that activation -- is deferred to the layer's grouped launch
-            dpre = self.T("tmp.dpre", rows, F) if self.group_wgrad else f1
+            dpre = self.TW("tmp.dpre", rows, F) if self.group_wgrad else f1
             self.lin_dgrad(dy, H, rows, W2, dpre, F, mode=L.EPI_MUL_POSMASK, aux_in=f1, ldaux=F, p=self.pdrop(p_inner))
         else:
             dpre = self.buf[f"{pre}.{lin1}.pre"]
@@ -597,7 +642,7 @@ class StepEngine:
             nxt = None
             if i > 0:
                 # consumed by the NEXT layer's first block, i.e. after this layer's flush: outside the per-layer rotation
-                nxt = (self.site(f"{stack}.layers.{i - 1}.linear2.drop"), self.pdrop(0.1), f"tmp.dy_carry{i & 1}")
+                nxt = (self.site(f"{stack}.layers.{i - 1}.linear2.drop"), self.pdrop(0.1), f"tmp.dy_carry{i % 3}")
             dy = self.attn_block_bwd(pre, "self_attn", "norm1", xs[2 * i], dres, ML, B, Lq, self.nh, mask, dy_in=dy, emit=nxt)
             self.flush_wgrads()
             yield i                                   # layer i's gradients are final
@@ -919,7 +964,7 @@ class StepEngine:
                                      rows_kv=MN, S=Nmem, d_mem=d_mem, mem_beta=0.0 if i == nl - 1 else 1.0, dy_in=dy,
                                      emit=(self.site(f"{pre}.self_attn.drop"), pd, self.dy_tag()))
             sh0 = self.share_layer0 and i == 0
-            nxt = (self.site(f"decoder.layers.{i - 1}.linear2.drop"), pd, f"tmp.dy_carry{i & 1}") if i > 0 else None
+            nxt = (self.site(f"decoder.layers.{i - 1}.linear2.drop"), pd, f"tmp.dy_carry{i % 3}") if i > 0 else None
             out = self.attn_block_bwd(pre, "self_attn", "norm1", xs[3 * i], dres, ML, B, Lq, self.nh, mask, shared=sh0,
                                       dy_in=dy, emit=None if sh0 else nxt)
             if sh0:
@@ -935,7 +980,7 @@ class StepEngine:
         call("vqh_colsum", dres, Lq * H, B, Lq * H, gq, 0.0, self.ws, self.ws.numel())
         if dx_sh is not None:
             call("vqh_add", gq, dx_sh, gq, Lq * H)
-        dmemf = self.T("tmp.dmemf", MN, H)
+        dmemf = self.TW("tmp.dmemf", MN, H)
         self.ln_bwd("mem_ln", d_mem, H, self.buf["dec.memf"], H, "mem_ln", dmemf, H, False, MN)
         self.lin_wgrad(dmemf, H, c["dec_z"], D, MN, self.G["from_code.weight"], self.G["from_code.bias"])
         self.lin_dgrad(dmemf, H, MN, self.P["from_code.weight"], d_z, D, beta=z_beta)
@@ -1083,6 +1128,7 @@ class StepEngine:
         """Backward as a generator over the phases of bwd_phases(): after the k-th yield, bucket self.buckets[k] of the flat
         gradient is final (its all-reduce may start)."""
         c = self.ctx
+        self._par = 0                                   # the same buffer names in every backward (graphs replay their own)
         for _ in self.decode_bwd_gen(c["d_rec"], c["d_ze"], 1.0 if self.m.use_vq else 0.0):
             yield
         c["d_hf"] = self.tokenize_bwd(c["d_ze"])
@@ -1093,6 +1139,7 @@ class StepEngine:
         yield
         for _ in self.encode_bwd_geo():
             yield
+        self.join_wgrads()
 
     def set_hyper(self, lr, weight_decay, max_norm, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, L_logical=0):
         """Host -> device scalars of the next optimizer step (copied on the current stream, outside any graph)."""

@@ -137,7 +137,8 @@ def test_vq_nearest_kernels_agree_and_match_fp64_argmin(R, K, D):
     assert int(got[0][5]) == 7
 
 
-@pytest.mark.parametrize("R,K,D", [(262144, 8192, 256), (65536, 1024, 128), (16384, 8192, 256), (24576, 2048, 128), (49152, 512, 256)])
+@pytest.mark.parametrize("R,K,D", [(262144, 8192, 256), (65536, 1024, 128), (16384, 8192, 256), (24576, 2048, 128), (49152, 512, 256),
+                                   (8192, 1024, 512)])
 def test_vq_nearest_plane_tensor_form_equals_the_register_form_and_the_fp64_argmin(R, K, D):
     """The plane-tensor score kernel (vq_nearest_p3_kernel: Z and the codebook pre-split, 256 x 128 tiles fed by LDS-DMA, top-2 in
     registers) is taken when the workspace allows it (vqh_vq_nearest_form == 3) and returns the indices of the register-resident
@@ -161,7 +162,7 @@ def test_vq_nearest_plane_tensor_form_equals_the_register_form_and_the_fp64_argm
     for flags in (0, 32):
         old = L.lib().vqh_vq_set_flags(flags)
         try:
-            assert L.lib().vqh_vq_nearest_form(R, K, D, ws.numel()) == (3 if flags == 0 else 2)
+            assert L.lib().vqh_vq_nearest_form(R, K, D, ws.numel()) == (3 if flags == 0 else 2 if D <= 256 else 0)
             idx = torch.full((R,), -1, device=DEV, dtype=torch.int64)
             L.call("vqh_vq_nearest", z, D, emb, D, idx, 0, R, K, D, 3e-5, ws, ws.numel())
             torch.cuda.synchronize()

@@ -327,9 +327,11 @@ def test_attention_short_sequence_kernels_equal_general_kernels(T, S, dh, p):
             assert rel(x, y) < 2e-6
 
 
-@pytest.mark.parametrize("T,S,p", [(350, 350, 0.1), (64, 350, 0.1), (200, 96, 0.0), (130, 257, 0.25)])
+@pytest.mark.parametrize("T,S,p", [(350, 350, 0.1), (64, 350, 0.1), (200, 96, 0.0), (130, 257, 0.25), (64, 64, 0.1), (40, 64, 0.25),
+                                   (64, 17, 0.0), (33, 31, 0.1), (7, 5, 0.1)])
 def test_attention_x3_kernels_equal_the_fp32_mfma_kernels(T, S, p):
-    """Head dim 64 beyond 64 queries / keys runs on the bf16 matrix pipes from exact 3-way operand splits (attention_x3.inc);
+    """Head dim 64 runs on the bf16 matrix pipes from exact 3-way operand splits (attention_x3.inc: the general kernels beyond 64
+    queries / keys, the fused short-sequence backward up to 64);
     vqh_attn_set_flags bit 2 keeps the native fp32 MFMA kernels.  Same masking, the SAME dropout masks (a dropped probability is
     dropped in both), results equal to fp32 round-off, and both as close to an fp64 evaluation."""
     L = _hip()
