@@ -410,3 +410,33 @@ def test_devices_resolution_and_single_command_launch(tmp_path):
     env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env1, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_vq_nearest_form_and_workspace_decisions():
+    """Host-side dispatch of vqh_vq_nearest (no kernel runs): which score kernel a (shape, workspace) pair gets and how much
+    workspace the fastest form wants.  The plane-tensor form needs whole 256-row / 128-code tiles, D in {128, 256, 512}, at
+    least 96 workgroups and the extra 1.5 (R + K) D + K + 6 ns R floats; with the documented minimum the round-2 forms run."""
+    import ctypes
+    from vqvae_hip import lib
+    L = lib.lib()
+    big = 1 << 40
+    assert L.vqh_vq_nearest_form(262144, 8192, 256, big) == 3
+    assert L.vqh_vq_nearest_form(8192, 1024, 512, big) == 3          # stage2_vq.yaml at B = 128: D = 512 has no register form
+    assert L.vqh_vq_nearest_form(262144, 8192, 256, 48 << 20) == 2   # workspace of round 2: the register-resident split form
+    assert L.vqh_vq_nearest_form(65536, 512, 64, big) == 2           # D = 64: too few K-steps per tile
+    assert L.vqh_vq_nearest_form(3000, 1000, 32, big) == 1           # fp32 MFMA, code tiles through LDS
+    assert L.vqh_vq_nearest_form(3000, 1000, 24, big) == 0           # D / 8 not a power of two: per-wave gather
+    assert L.vqh_vq_nearest_form(4096, 4096, 512, big) == 3          # 16 row tiles x 8 code ranges = 128 workgroups
+    assert L.vqh_vq_nearest_form(1024, 4096, 512, big) == 0          # 4 row tiles: per-wave gather
+    assert L.vqh_vq_nearest_form(262144 + 8, 8192, 256, big) == 2    # ragged row count
+    need = lib.vq_nearest_workspace(262144, 8192, 256)
+    base = lib.vq_nearest_workspace(262144 + 8, 8192, 256)           # same shape class without the plane-tensor extra
+    extra = 3 * 262144 * 256 // 2 + 3 * 8192 * 256 // 2 + 8192 + 6 * 8 * 262144 + 16
+    assert need - extra > 0 and abs((need - extra) - base) < 64
+    assert L.vqh_vq_nearest_form(262144, 8192, 256, need) == 3 and L.vqh_vq_nearest_form(262144, 8192, 256, need - 1) == 2
+    old = L.vqh_vq_set_flags(32)                                     # A/B switch: never the plane-tensor form
+    try:
+        assert L.vqh_vq_nearest_form(262144, 8192, 256, big) == 2
+        assert lib.vq_nearest_workspace(262144, 8192, 256) == need - extra
+    finally:
+        L.vqh_vq_set_flags(old)
