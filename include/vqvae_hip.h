@@ -188,8 +188,8 @@ int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* 
                  float* dV, int lddv, const unsigned char* kvalid, int B, int nh, int T, int S, int dh, int qkv_shared,
                  const unsigned long long* rng_state, unsigned drop_site, float drop_p, vqh_stream_t stream);
 /* diagnostic: bit 0 = do not use the fused short-sequence (T,S <= 64) kernels; bit 1 = short-sequence backward in its
- * round-1 two-wave-group form instead of the quartered one; bit 2 = the kernels of head dim 64 (general ones and the short-sequence
- * backward) on the native fp32 MFMA instead of the bf16 pipes fed by exact 3-way operand splits (A/B runs: same results to fp32
+ * round-1 two-wave-group form instead of the quartered one; bit 2 = the kernels of head dim 64 (general and short-sequence
+ * ones) on the native fp32 MFMA instead of the bf16 pipes fed by exact 3-way operand splits (A/B runs: same results to fp32
  * round-off); returns the previous flags */
 int vqh_attn_set_flags(int flags);
 

@@ -958,6 +958,19 @@ extern "C" int vqh_attn_fwd(const float* Q, int ldq, const float* K, int ldk, co
     a.drop = make_drop(rng_state, drop_site, drop_p);
     if (T <= 64 && S <= 64 && aligned16(O, ldo) && !(g_attn_flags & 1)) {
         dim3 grid(1, nh, B);
+        if (dh == 64 && !(g_attn_flags & (2 | 4))) {           // bf16 matrix pipes on exactly split operands (attention_x3.inc)
+            static bool attr_set = false;
+            const int smem = 2 * ax::IMG + 2 * 128 * 4;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_small_x3_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(attn_fwd_small_x3_kernel, grid, dim3(256), smem, stream, a);
+            VQH_LAUNCH_CHECK();
+            return VQH_OK;
+        }
         if (!(g_attn_flags & 2)) {                   // quartered form: 4 waves, one 32 x 32 quarter each
             switch (dh) {
                 case 16: hipLaunchKernelGGL((attn_fwd_small4_kernel<16>), grid, dim3(256), 0, stream, a); break;
@@ -1028,10 +1041,10 @@ extern "C" int vqh_attn_bwd(const float* Q, int ldq, const float* K, int ldk, co
         int rc = VQH_OK;
         if (dh == 64 && !(g_attn_flags & (2 | 4))) {           // bf16 matrix pipes on exactly split operands (attention_x3.inc)
             static bool attr_set = false;
-            const int smem = 3 * ax::IMG + 3 * 64 * 4;
+            const int smem = 2 * 64 * (ax::DH + 4) * 4 + 64 * (ax::DH + 4) * 4;       // three fp32 result tiles > two images + row scalars
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_x3_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
                 if (e != hipSuccess) { vqh_set_error(hipGetErrorString(e)); return VQH_ERR_LAUNCH; }
                 attr_set = true;
             }
