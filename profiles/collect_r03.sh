@@ -3,7 +3,7 @@
 # (stage2_vq.yaml at B = 128, L = 350) and the VQ-only bench; then the counter passes, each its own run with no other trace
 # domain: FETCH_SIZE / WRITE_SIZE for C2 and for the VQ-only bench, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE for both.
 # Output goes to gpurun_out/r03/ ; the summaries are then copied into profiles/ by hand (see profiles/README.md).
-# Usage: collect_r03.sh [stats|pmc|all]
+# Usage: collect_r03.sh [stats|pmc|all|c2]
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$R/gpurun_out/r03"
@@ -23,6 +23,15 @@ pmc() {     # name, counters, bench args...
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/pmc_$name" -- python3 "$R/bench.py" "$@" --no-graph --no-cpu-baseline > "$OUT/pmc_$name.log" 2>&1 || echo "pmc $name failed"
   echo "[collect] pmc $name done"
 }
+if [ "$WHAT" = "c2" ]; then
+  stats c2 --workload c2 --steps 5 --warmup 3
+  pmc c2_fetch FETCH_SIZE --steps 2 --warmup 3
+  pmc c2_write WRITE_SIZE --steps 2 --warmup 3
+  python3 "$R/profiles/make_pmc_json.py" "$OUT/pmc_c2_fetch" "$OUT/pmc_c2_write" "$OUT/r03_c2_pmc_traffic.json"
+  pmc c2_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --steps 2 --warmup 3
+  python3 "$R/profiles/make_mfma_json.py" "$OUT/pmc_c2_mfma" "$OUT/r03_c2_pmc_mfma_busy.json"
+  rm -rf "$OUT"/pmc_*/
+fi
 if [ "$WHAT" = "stats" ] || [ "$WHAT" = "all" ]; then
   stats c2 --workload c2 --steps 5 --warmup 3
   stats c5 --workload c5 --steps 5 --warmup 3
