@@ -99,6 +99,10 @@ int vqh_gemm_set_flags(int flags);
  * MFMA), writing fp32 (C), a plane tensor (Cp) or both; shapes must satisfy vqh_gemm_p3_eligible (M % 256, N % 128, K % 32).
  * sign_bits: EPI_RELU_DROP writes, EPI_MUL_POSMASK reads 1 bit per output (v > 0) in the kernel's own order (M * N / 8 bytes),
  * instead of an fp32 copy of the activation.  Layouts: (a_kcontig, b_kcontig) = (1, 1) forward, (1, 0) dgrad, (0, 0) wgrad.
+ * STAGE IMAGES (pitch 0 in vqh_p3_split and for the A / B operands of vqh_gemm_p3): the same planes stored as the 1 KB units the
+ * kernel's LDS-DMA moves -- [R / 256][C / 32][16 row blocks][3 planes][64 lanes x 16 B], lane L of a unit = row L >> 2 of the
+ * block, 16-byte chunk (L & 3) ^ F((L >> 4) & 3), F = (0, 2, 3, 1) -- so that every DMA instruction reads consecutive memory
+ * (R % 256 == 0; same size, same values, bit-identical results; one image serves the k-contiguous and the row-contiguous use).
  * ------------------------------------------------------------------------------------------- */
 int vqh_p3_split(const float* X, int ldx, void* P, long long pitch_bytes, int rows, int cols, vqh_stream_t stream);
 typedef struct vqh_p3_item_t { const float* X; void* P; int rows, cols; long long ldx, pitch_bytes; } vqh_p3_item_t;

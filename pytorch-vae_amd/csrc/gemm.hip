@@ -1210,6 +1210,16 @@ extern "C" int vqh_gemm_wgrad_group(int n, const vqh_wgrad_t* pr, float* workspa
 extern "C" int vqh_p3_split(const float* X, int ldx, void* P, long long pitch_bytes, int rows, int cols, hipStream_t stream) {
     if (rows <= 0 || cols <= 0) return VQH_OK;
     VQH_CHECK_ARG(X && P, "vqh_p3_split: null pointer");
+    if (pitch_bytes == 0) {                 // stage images: [rows / 256][cols / 32][16 row blocks][3 planes][1 KB]
+        VQH_CHECK_ARG((rows % 256) == 0 && (cols % 32) == 0 && ldx >= cols && (ldx & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P)) & 15) == 0,
+                      "vqh_p3_split: stage images need rows % 256 == 0, cols % 32 == 0, ldx % 4 == 0 and 16-byte alignment");
+        const long long tot = (long long)rows * (cols >> 3);
+        hipLaunchKernelGGL(p3_split_tiled_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 1 << 16)), dim3(256), 0, stream, X,
+                           (long long)ldx, reinterpret_cast<char*>(P), rows, cols, 256);
+        VQH_LAUNCH_CHECK();
+        return VQH_OK;
+    }
     VQH_CHECK_ARG((cols % 32) == 0 && ldx >= cols && (ldx & 3) == 0 && pitch_bytes >= (long long)cols * 6 && (pitch_bytes % 16) == 0 &&
                   ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P)) & 15) == 0,
                   "vqh_p3_split: cols % 32, ldx % 4, 16-byte alignment and pitch >= 6 * cols required");
@@ -1287,6 +1297,7 @@ int launch_p3(const P3Args& g, int splits, hipStream_t stream) {
     return VQH_OK;
 }
 inline bool p3_tensor_ok(const void* P, long long pitch, int cols) {
+    if (pitch == 0) return P && (reinterpret_cast<uintptr_t>(P) & 15) == 0;          // stage images (rows % 256 checked by the caller)
     return P && (reinterpret_cast<uintptr_t>(P) & 15) == 0 && (pitch % 16) == 0 && pitch >= (long long)cols * 6;
 }
 }  // namespace
@@ -1366,6 +1377,10 @@ extern "C" int vqh_gemm_p3(int a_kcontig, int b_kcontig, int M, int N, int K, co
     VQH_CHECK_ARG(mode >= EPI_LINEAR && mode <= EPI_MUL_SIGGRAD, "vqh_gemm_p3: unknown epilogue mode");
     VQH_CHECK_ARG(p3_tensor_ok(Ap, pitch_a, a_kcontig ? K : M) && p3_tensor_ok(Bp, pitch_b, b_kcontig ? K : N),
                   "vqh_gemm_p3: operand plane tensor (alignment / pitch)");
+    // pitch 0 = stage images (256-row tiles): the operand's row count must be a multiple of 256
+    VQH_CHECK_ARG(pitch_a != 0 || ((a_kcontig ? M : K) % 256) == 0, "vqh_gemm_p3: stage-image A needs rows % 256 == 0");
+    VQH_CHECK_ARG(pitch_b != 0 || ((b_kcontig ? N : K) % 256) == 0, "vqh_gemm_p3: stage-image B needs rows % 256 == 0");
+    VQH_CHECK_ARG(!Cp || pitch_c != 0, "vqh_gemm_p3: stage-image OUTPUT is not implemented");
     VQH_CHECK_ARG(C || Cp, "vqh_gemm_p3: no output");
     VQH_CHECK_ARG(!C || (ldc >= N && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0), "vqh_gemm_p3: C alignment / ldc");
     VQH_CHECK_ARG(!Cp || p3_tensor_ok(Cp, pitch_c, N), "vqh_gemm_p3: output plane tensor (alignment / pitch)");

@@ -268,6 +268,18 @@ def p3_split(X, P=None):
     return P
 
 
+def p3_image(X, P=None):
+    """fp32 matrix [rows % 256 == 0, cols % 32 == 0] -> its STAGE IMAGES (pitch 0 in the vqh_gemm_p3* calls): int16 tensor of
+    rows * cols * 3 elements laid out [rows / 256][cols / 32][16 row blocks][3 planes][64 lanes x 16 B]."""
+    rows, cols = X.shape
+    if rows % 256 or cols % 32:
+        raise VqhError(f"stage images need rows % 256 == 0 and cols % 32 == 0 (got {rows} x {cols})")
+    if P is None:
+        P = torch.empty(rows * cols * 3, device=X.device, dtype=torch.int16)
+    call("vqh_p3_split", X, int(X.stride(0)), P, 0, int(rows), int(cols))
+    return P
+
+
 def p3_to_float(P):
     """Plane tensor -> fp32 matrix h + m + l (host-side check helper; exact)."""
     f = (P.to(torch.int32) << 16).view(torch.float32)          # bf16 bits -> fp32

@@ -212,3 +212,27 @@ def test_p3_small_magnitudes_and_ineligible_shapes():
         assert e <= (bound if bound is not None else 2.0 ** -21), (log2s, e)
     with pytest.raises(L.VqhError):
         L.gemm_p3(1, 1, 128, 128, 32, L.p3_split(_rand((128, 32), 1)), L.p3_split(_rand((128, 32), 2)), torch.empty(128, 128, device=DEV), 128)
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (1024, 512, 1280), (256, 256, 4096)])
+def test_gemm_p3_on_stage_images_equals_plane_tensors(akc, bkc, M, N, K):
+    """Operands as STAGE IMAGES (pitch 0: 256-row tiles of [16 rows][64 B] blocks, every LDS-DMA instruction reads 1 KB of
+    consecutive memory) give bit-identical results to the row-pitched plane tensors: same values, same order of operations.
+    All three operand layouts of the step (forward, dgrad, weight gradient), with and without split-K."""
+    L = _hip()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + akc * 2 + bkc)
+    A = torch.randn((M, K) if akc else (K, M), generator=g).to(DEV)
+    B = (torch.randn((N, K) if bkc else (K, N), generator=g) / K ** 0.5).to(DEV)
+    ws = torch.empty(8 << 20, device=DEV)
+    Ap, Bp = L.p3_split(A), L.p3_split(B)
+    Ai, Bi = L.p3_image(A), L.p3_image(B)
+    want = torch.empty(M, N, device=DEV)
+    L.gemm_p3(akc, bkc, M, N, K, Ap, Bp, want, N, ws=ws)
+    for (a, pa), (b, pb) in (((Ai, 0), (Bi, 0)), ((Ai, 0), (Bp, None)), ((Ap, None), (Bi, 0))):
+        got = torch.full((M, N), float("nan"), device=DEV)
+        L.gemm_p3(akc, bkc, M, N, K, a, b, got, N, ws=ws, pitch_a=pa, pitch_b=pb)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), float((got - want).abs().max())
+    ref = (A.double() if akc else A.double().t()) @ (B.double().t() if bkc else B.double())
+    assert float((want.double() - ref).abs().max() / ref.abs().max()) < 2e-6
